@@ -1,0 +1,127 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front-end of the plain-C restatement (``oracle_passive.c``) and loader of
+the real reference extension built into ``oracle/_ref`` by ``oracle/Makefile``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module; nothing in ``simplestereo_amd/`` does.
+
+Parity pinning: the C restatement is checked bit-exactly against golden maps
+produced by the unmodified reference (``tests/golden/make_golden.py``); see
+``tests/test_oracle_golden.py``.
+"""
+import ctypes
+import importlib.util
+import os
+import subprocess
+import sysconfig
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle_passive.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "oracle_passive.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_passive.so"])
+    if os.path.exists("/root/reference/simplestereo/_passive.cpp") and (force or ref_module() is None):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        lib = ctypes.CDLL(_LIB)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        lib.oracle_asw.restype = ctypes.c_int
+        lib.oracle_asw.argtypes = [u8p, u8p] + [ctypes.c_int] * 5 + [ctypes.c_double] * 2 + \
+            [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_double)]
+        lib.oracle_gsw.restype = ctypes.c_int
+        lib.oracle_gsw.argtypes = [u8p, u8p] + [ctypes.c_int] * 6 + [ctypes.c_float] + \
+            [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int16)]
+        lib.oracle_bgr2lab.restype = None
+        lib.oracle_bgr2lab.argtypes = [u8p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
+        _lib = lib
+    return _lib
+
+
+def _img(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("oracle expects uint8 [H,W,3]")
+    return a
+
+
+def _u8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def asw(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5,
+        consistent=False, hoist=True, nthreads=0, return_costs=False):
+    """C restatement of ``_passive.computeASW`` (reference _passive.cpp:293-400)."""
+    lib = _load()
+    a, b = _img(img1), _img(img2)
+    H, W = a.shape[:2]
+    out = np.empty((H, W), np.int16)
+    costs = None
+    cptr = ctypes.POINTER(ctypes.c_double)()
+    if return_costs:
+        costs = np.empty((H, W, maxDisparity - minDisparity + 1), np.float64)
+        cptr = costs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rc = lib.oracle_asw(_u8(a), _u8(b), H, W, winSize, maxDisparity, minDisparity,
+                        float(gammaC), float(gammaP), int(bool(consistent)), int(bool(hoist)),
+                        int(nthreads), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), cptr)
+    if rc != 0:
+        raise RuntimeError("oracle_asw failed rc=%d" % rc)
+    return (out, costs) if return_costs else out
+
+
+def gsw(img1, img2, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120,
+        iterations=3, bins=20, closed=False, nthreads=0):
+    """C restatement of ``_passive.computeGSW`` (reference _passive.cpp:703-774)."""
+    lib = _load()
+    a, b = _img(img1), _img(img2)
+    H, W = a.shape[:2]
+    out = np.empty((H, W), np.int16)
+    rc = lib.oracle_gsw(_u8(a), _u8(b), H, W, winSize, maxDisparity, minDisparity, int(gamma),
+                        float(fMax), int(iterations), int(bins), int(bool(closed)), int(nthreads),
+                        out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)))
+    if rc != 0:
+        raise RuntimeError("oracle_gsw failed rc=%d" % rc)
+    return out
+
+
+def bgr2lab(img):
+    """C restatement of ColorConversion::ImageFromBGR2Lab (colorconversion.hpp:81-86)."""
+    lib = _load()
+    a = _img(img)
+    H, W = a.shape[:2]
+    lab = np.empty((H, W, 3), np.float64)
+    lib.oracle_bgr2lab(_u8(a), lab.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), W, H)
+    return lab
+
+
+_ref = False
+
+
+def ref_module():
+    """The real reference extension (``_passive``) from oracle/_ref, or None."""
+    global _ref
+    if _ref is False:
+        path = os.path.join(_HERE, "_ref", "_passive" + sysconfig.get_config_var("EXT_SUFFIX"))
+        _ref = None
+        if os.path.exists(path):
+            try:
+                spec = importlib.util.spec_from_file_location("_passive", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _ref = mod
+            except Exception:
+                _ref = None
+    return _ref

@@ -1,0 +1,62 @@
+"""pytest configuration: the `gpu` marker and shared golden-vector fixtures."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tsukuba():
+    z = np.load(os.path.join(GOLDEN, "tsukuba_pair.npz"))
+    return {k: np.ascontiguousarray(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden_inputs(tsukuba):
+    from simplestereo_amd.synth import make_pair
+    L, R = tsukuba["left"], tsukuba["right"]
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name == "tsukuba":
+                cache[name] = (L, R)
+            elif name == "crop":
+                cache[name] = (np.ascontiguousarray(L[100:118, 150:190]), np.ascontiguousarray(R[100:118, 150:190]))
+            elif name == "tsukuba_top":
+                cache[name] = (np.ascontiguousarray(L[:40]), np.ascontiguousarray(R[:40]))
+            elif name == "synth_96x128":
+                cache[name] = make_pair(96, 128, 32, 0)[:2]
+            elif name == "synth_64x96":
+                cache[name] = make_pair(64, 96, 24, 5)[:2]
+            elif name == "synth_480x640":
+                cache[name] = make_pair(480, 640, 64, 0)[:2]
+            else:
+                raise KeyError(name)
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    maps = np.load(os.path.join(GOLDEN, "cases.npz"))
+    with open(os.path.join(GOLDEN, "cases.json")) as f:
+        meta = json.load(f)
+    return maps, meta
+
+
+@pytest.fixture(scope="session")
+def golden_errors():
+    with open(os.path.join(GOLDEN, "errors.json")) as f:
+        return json.load(f)

@@ -1,0 +1,103 @@
+"""Tier T1: the CPU oracle (oracle/oracle_passive.c) == golden vectors made by the
+unmodified reference (tests/golden/make_golden.py), bit-exact on int16 maps.
+This is what pins the oracle; everything GPU-side is then compared to the oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLDEN, "cases.json")) as _f:
+    _META = json.load(_f)
+_SLOW_LITERAL = {"G6f", "G3", "G4"}        # literal mode too slow for the CPU suite budget
+
+
+def _run(cid, meta, inputs, fast):
+    a, b = inputs(meta["input"])
+    p = dict(meta["params"])
+    algo = p.pop("algo")
+    if algo == "asw":
+        return oracle.asw(a, b, hoist=fast, **p)
+    return oracle.gsw(a, b, closed=fast, **p)
+
+
+def test_golden_inputs_unchanged(golden_cases, golden_inputs):
+    """the seeded generator / stored Tsukuba arrays still produce the bytes the reference saw"""
+    _, meta = golden_cases
+    for cid, m in meta.items():
+        a, b = golden_inputs(m["input"])
+        assert hashlib.sha256(a.tobytes() + b.tobytes()).hexdigest() == m["input_sha256"], cid
+
+
+def test_golden_maps_match_their_recorded_hash(golden_cases):
+    maps, meta = golden_cases
+    for cid, m in meta.items():
+        assert hashlib.sha256(maps[cid].tobytes()).hexdigest() == m["sha256"], cid
+    # the ids SURVEY.md section 8c recorded from an independent build of the reference
+    assert meta["G1"]["sha256"].startswith("32251741b4cb6ca7")
+    assert meta["G2"]["sha256"].startswith("491614144244234a")
+    assert meta["G3"]["sha256"].startswith("72b2441d422da9e6")
+    assert meta["G4"]["sha256"].startswith("cbced3a6a04b71d7")
+
+
+@pytest.mark.parametrize("cid", sorted(_META))
+def test_oracle_fast_modes_bit_exact(cid, golden_cases, golden_inputs):
+    """hoisted ASW windows / closed-form GSW weights reproduce the reference bit-exactly"""
+    maps, meta = golden_cases
+    d = _run(cid, meta[cid], golden_inputs, fast=True)
+    assert d.dtype == np.int16
+    assert np.array_equal(d, maps[cid])
+
+
+@pytest.mark.parametrize("cid", sorted(set(_META) - _SLOW_LITERAL))
+def test_oracle_literal_bit_exact(cid, golden_cases, golden_inputs):
+    """literal mode: same loop structure and libm work as _passive.cpp"""
+    maps, meta = golden_cases
+    d = _run(cid, meta[cid], golden_inputs, fast=False)
+    assert np.array_equal(d, maps[cid])
+
+
+def test_oracle_thread_count_independent(golden_inputs):
+    a, b = golden_inputs("synth_64x96")
+    d1 = oracle.asw(a, b, winSize=9, maxDisparity=12, consistent=True, nthreads=1)
+    d3 = oracle.asw(a, b, winSize=9, maxDisparity=12, consistent=True, nthreads=3)
+    assert np.array_equal(d1, d3)
+
+
+def test_oracle_cost_dump_consistent_with_wta(golden_inputs):
+    a, b = golden_inputs("crop")
+    d, c = oracle.asw(a, b, winSize=7, maxDisparity=6, minDisparity=1, return_costs=True)
+    H, W = d.shape
+    for y in range(H):
+        for x in range(W):
+            row = c[y, x]
+            ok = ~np.isnan(row)
+            if not ok.any():
+                assert d[y, x] == x          # empty candidate loop -> dBest stays 0 (_passive.cpp:54,98)
+                continue
+            assert d[y, x] == 1 + int(np.nanargmin(row))   # first (smallest) disparity wins ties
+            assert ok.sum() == min(6, x) - 1 + 1
+
+
+def test_oracle_lab_known_values():
+    """colorconversion.hpp:18-70 on a few bytes with textbook Lab values"""
+    px = np.array([[[0, 0, 0], [255, 255, 255], [0, 0, 255], [255, 0, 0]]], np.uint8)   # BGR
+    lab = oracle.bgr2lab(px)[0]
+    assert np.allclose(lab[0], [0, 0, 0], atol=1e-4)
+    assert np.allclose(lab[1], [100.0, 0.0053, -0.0104], atol=2e-2)       # white (D65 rounding of the matrix)
+    assert np.allclose(lab[2], [53.2408, 80.0925, 67.2032], atol=2e-2)    # pure red
+    assert np.allclose(lab[3], [32.2970, 79.1875, -107.8602], atol=2e-2)  # pure blue
+
+
+def test_reference_module_agrees_when_present(golden_cases, golden_inputs):
+    ref = oracle.ref_module()
+    if ref is None:
+        pytest.skip("oracle/_ref not built on this box")
+    maps, _ = golden_cases
+    a, b = golden_inputs("crop")
+    d = ref.computeASW(a, b, 7, 6, 1, 5.0, 17.5, True)
+    assert np.array_equal(d, maps["G5c"])
