@@ -1,0 +1,124 @@
+/*
+ * ssamd.h -- C ABI of libssamd.so, the MI355X (gfx950) implementation of the
+ * SimpleStereo passive-matching hot path (Adaptive / Geodesic Support-Weight
+ * stereo).  Plain pointers and sizes only: this is the drop-in boundary a
+ * maintainer of the reference would bind instead of the CPython extension
+ * `simplestereo._passive` (see INTEGRATION.md for the ctypes stub).
+ *
+ * Reference interface each entry point replaces (paths under the reference repo):
+ *
+ *   ssamd_asw          <->  _passive.computeASW   simplestereo/_passive.cpp:293-400
+ *                           called from StereoASW.compute, passive.py:88-90
+ *   ssamd_gsw          <->  _passive.computeGSW   simplestereo/_passive.cpp:703-774
+ *                           called from StereoGSW.compute, passive.py:153-156
+ *   ssamd_*_device     same operators on buffers already resident in HBM (no
+ *                      reference counterpart: the reference has no device).
+ *
+ * Conventions
+ *   - images: uint8, C-contiguous [height][width][3], channel order B,G,R
+ *     (what cv2.imread returns; _passive.cpp:333-334 assumes the same).
+ *   - disparity: int16, C-contiguous [rows][width], caller-allocated.
+ *   - every function returns 0 on success or a negative SSAMD_E* code; a
+ *     human-readable message for the calling thread is at ssamd_last_error().
+ *   - the library never keeps a caller pointer after returning.
+ *   - calls are serialised per process by an internal mutex (ctypes releases the
+ *     GIL during the call, the reference holds it: blocking semantics are kept).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with SSAMD_ENODEVICE.
+ */
+#ifndef SSAMD_H
+#define SSAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSAMD_ABI_VERSION 1
+
+#define SSAMD_OK 0
+#define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
+#define SSAMD_ENODEVICE (-2)  /* no usable HIP device                          */
+#define SSAMD_EHIP (-3)       /* a HIP runtime call failed                     */
+#define SSAMD_ENOMEM (-4)     /* device or host allocation failed              */
+#define SSAMD_ELIMIT (-5)     /* parameters exceed what the kernels support    */
+
+int ssamd_abi_version(void);
+const char *ssamd_last_error(void);
+/* number of visible HIP devices (0 if none / runtime unavailable) */
+int ssamd_device_count(void);
+
+/* ---- host-buffer operators (H2D copy, kernels, D2H copy, synchronous) ------ */
+
+/* Adaptive Support-Weight matching; argument meaning as _passive.computeASW
+ * ("O!O!iiidd|p", _passive.cpp:301).  device: HIP device ordinal, or -1 for the
+ * current device. */
+int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width,
+              int winSize, int maxDisparity, int minDisparity,
+              double gammaC, double gammaP, int consistent,
+              int16_t *disparity, int device);
+
+/* Geodesic Support-Weight matching; argument meaning as _passive.computeGSW
+ * ("O!O!iiiifii", _passive.cpp:709).  `bins` is accepted and unused, like the
+ * reference (workerGSW never reads it). */
+int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width,
+              int winSize, int maxDisparity, int minDisparity,
+              int gamma, float fMax, int iterations, int bins,
+              int16_t *disparity, int device);
+
+/* ---- device-buffer operators (asynchronous on `stream`) -------------------- */
+/* d_img1/d_img2: device pointers to a [height][width][3] sub-image (for a row
+ * strip: the strip plus its winSize/2 halo rows).  Rows [out_row0,
+ * out_row0+out_rows) of that sub-image are matched and written to d_disparity
+ * ([out_rows][width]).  Image borders are the sub-image borders, so a strip that
+ * carries its full halo reproduces the whole-image result exactly.
+ * stream: a hipStream_t (NULL = the null stream).  The caller synchronises. */
+int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                     int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity,
+                     double gammaC, double gammaP, int consistent,
+                     int16_t *d_disparity, void *stream);
+
+int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                     int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity,
+                     int gamma, float fMax, int iterations, int bins,
+                     int16_t *d_disparity, void *stream);
+
+/* ---- verification / measurement helpers ------------------------------------ */
+
+/* Raw left-referenced aggregated ASW costs, float32 [height][width][nD] with
+ * nD = maxDisparity-minDisparity+1, NaN where the reference evaluates no
+ * candidate (x-d < 0).  Host buffers, synchronous.  For tolerance tests. */
+int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    double gammaC, double gammaP, float *costs, int device);
+
+/* CIELab conversion used by ASW (replaces ColorConversion::ImageFromBGR2Lab,
+ * headers/colorconversion.hpp:81-86); float32 [height][width][3]. Host buffers. */
+int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device);
+
+/* Kernel timing with HIP events recorded on the launch stream.  After
+ * ssamd_profile_enable(1) every operator call brackets its kernels with events;
+ * ssamd_profile_read() synchronises and returns accumulated milliseconds and
+ * launch counts per kernel slot since the last ssamd_profile_reset(). */
+#define SSAMD_K_LAB 0        /* bgr2lab records                                  */
+#define SSAMD_K_ASW_AGG 1    /* ASW cost aggregation + WTA keys (dominant)       */
+#define SSAMD_K_ASW_FIN 2    /* ASW key decode / LR check / occlusion fill       */
+#define SSAMD_K_GSW_AGG 3    /* GSW weights + cost aggregation + WTA keys        */
+#define SSAMD_K_GSW_FIN 4    /* GSW LR check / occlusion fill                    */
+#define SSAMD_K_COUNT 5
+int ssamd_profile_enable(int on);
+int ssamd_profile_reset(void);
+int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);
+const char *ssamd_kernel_name(int slot);
+
+/* Launch geometry chosen for an ASW problem (for DESIGN.md / bench reporting).
+ * out[0..7] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y, grid_z */
+int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAMD_H */

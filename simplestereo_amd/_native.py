@@ -1,0 +1,86 @@
+"""ctypes binding of libssamd.so (C ABI in include/ssamd.h).
+
+This is the only place Python touches the native library.  There is no Python or
+CPU fallback for the operators: if the library is missing, or no HIP device is
+visible, the calls fail loudly.
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_COUNT = 0, 1, 2, 3, 4, 5
+
+_lib = None
+_u8p = ctypes.c_void_p
+_i16p = ctypes.c_void_p
+
+
+class NativeError(RuntimeError):
+    """A libssamd call returned an error code."""
+
+    def __init__(self, code, msg):
+        super().__init__("libssamd error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+def lib():
+    """Load libssamd.so (once).  Raises ImportError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "simplestereo_amd: native library %s is missing. Build it with "
+            "`python -m simplestereo_amd.build` (needs hipcc, targets gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    I, D, F, P = ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_void_p
+    L.ssamd_abi_version.restype = I
+    L.ssamd_last_error.restype = ctypes.c_char_p
+    L.ssamd_device_count.restype = I
+    L.ssamd_asw.restype = I
+    L.ssamd_asw.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
+    L.ssamd_gsw.restype = I
+    L.ssamd_gsw.argtypes = [P, P, I, I, I, I, I, I, F, I, I, P, I]
+    L.ssamd_asw_device.restype = I
+    L.ssamd_asw_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_gsw_device.restype = I
+    L.ssamd_gsw_device.argtypes = [P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]
+    L.ssamd_asw_costs.restype = I
+    L.ssamd_asw_costs.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
+    L.ssamd_bgr2lab.restype = I
+    L.ssamd_bgr2lab.argtypes = [P, I, I, P, I]
+    L.ssamd_profile_enable.restype = I
+    L.ssamd_profile_enable.argtypes = [I]
+    L.ssamd_profile_reset.restype = I
+    L.ssamd_profile_read.restype = I
+    L.ssamd_profile_read.argtypes = [ctypes.POINTER(D), ctypes.POINTER(ctypes.c_longlong)]
+    L.ssamd_kernel_name.restype = ctypes.c_char_p
+    L.ssamd_kernel_name.argtypes = [I]
+    L.ssamd_asw_geometry.restype = I
+    L.ssamd_asw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
+    if L.ssamd_abi_version() != 1:
+        raise ImportError("libssamd ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(rc, lib().ssamd_last_error().decode("utf-8", "replace"))
+
+
+def profile_read():
+    ms = (ctypes.c_double * K_COUNT)()
+    n = (ctypes.c_longlong * K_COUNT)()
+    check(lib().ssamd_profile_read(ms, n))
+    return list(ms), list(n)
+
+
+def asw_geometry(width, rows, winSize, maxDisparity, minDisparity):
+    out = (ctypes.c_int * 8)()
+    check(lib().ssamd_asw_geometry(width, rows, winSize, maxDisparity, minDisparity, out))
+    keys = ("tile_x", "chunk_d", "n_chunks", "threads", "lds_bytes", "grid_x", "grid_y", "grid_z")
+    return dict(zip(keys, list(out)))

@@ -1,0 +1,485 @@
+// libssamd.so: host side of the C ABI declared in include/ssamd.h (gfx950 / ROCm).
+// Owns device scratch, chooses launch geometry, launches the HIP kernels.
+// There is deliberately no CPU code path for the operators in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ssamd.h"
+#include "asw_kernels.hip.h"
+#include "gsw_kernels.hip.h"
+#include "lab_kernels.hip.h"
+
+using namespace ssamd;
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mutex;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? SSAMD_ENOMEM : SSAMD_EHIP, "%s failed: %s",    \
+                        #expr, hipGetErrorString(e_));                                             \
+    } while (0)
+
+// ------------------------------------------------------------------ scratch
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SSAMD_OK;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) { ptr = nullptr; return fail(SSAMD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return SSAMD_OK;
+    }
+};
+
+struct Profile {
+    bool on = false;
+    struct Pair { hipEvent_t a, b; int slot; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[SSAMD_K_COUNT] = {0};
+    long long n[SSAMD_K_COUNT] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void drain()
+    {
+        for (auto &p : pending) {
+            float t = 0.f;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+                ms[p.slot] += t;
+                n[p.slot] += 1;
+            }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+struct Ctx {
+    int dev = -1;
+    bool lut_ready = false;
+    hipStream_t stream = nullptr;       // used by the host-buffer entry points
+    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, prox, costs, gswTab, lab;
+    // cached small tables
+    int prox_win = -1; double prox_gammaP = -1;
+    int gsw_gamma = -1; float gsw_fmax = -1.f;
+    Profile prof;
+};
+
+Ctx g_ctx[16];
+
+struct Timed {   // brackets one kernel launch with events when profiling is on
+    Ctx &c; hipStream_t s; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Timed(Ctx &c_, hipStream_t s_, int slot_) : c(c_), s(s_), slot(slot_)
+    {
+        if (c.prof.on) { a = c.prof.get(); b = c.prof.get(); (void)hipEventRecord(a, s); }
+    }
+    ~Timed()
+    {
+        if (a) { (void)hipEventRecord(b, s); c.prof.pending.push_back({a, b, slot}); }
+    }
+};
+
+int get_ctx(int device, Ctx **out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SSAMD_ENODEVICE, "no HIP device visible: libssamd has no CPU fallback");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n || device >= 16) return fail(SSAMD_EINVAL, "device ordinal %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    Ctx &c = g_ctx[device];
+    if (c.dev < 0) {
+        c.dev = device;
+        HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    }
+    if (!c.lut_ready) {
+        // sRGB byte -> linear*100 in the reference's float arithmetic (colorconversion.hpp:19-37)
+        float lut[256];
+        for (int v = 0; v < 256; ++v) {
+            float x = v / 255.0;
+            if (x > 0.04045) x = powf((x + 0.055) / 1.055, 2.4);
+            else x /= 12.92;
+            x *= 100;
+            lut[v] = x;
+        }
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_lin100), lut, sizeof(lut)));
+        c.lut_ready = true;
+    }
+    *out = &c;
+    return SSAMD_OK;
+}
+
+int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
+{
+    if (H <= 0 || W <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (!(win > 0 && win % 2 == 1)) return fail(SSAMD_EINVAL, "winSize must be a positive odd number!");
+    if (minD < 0) return fail(SSAMD_EINVAL, "minDisparity must be >= 0 (negative values are undefined behaviour in the reference)");
+    if (W > 32767 || maxD > 32767) return fail(SSAMD_ELIMIT, "width / maxDisparity exceed the int16 disparity range");
+    if (row0 < 0 || rows < 0 || row0 + rows > H) return fail(SSAMD_EINVAL, "output row range [%d,%d) outside the image (height %d)", row0, row0 + rows, H);
+    if (win > 255) return fail(SSAMD_ELIMIT, "winSize %d > 255 not supported", win);
+    return SSAMD_OK;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------ ASW geometry
+bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
+{
+    const int p = win / 2;
+    g.XG = XG; g.DG = DG;
+    g.Tx = ASW_RX * XG; g.Dc = ASW_RD * DG;
+    g.threads = round_up(XG * DG, 64);
+    g.nL = g.Tx + 2 * p;
+    g.nRc = g.Tx + g.Dc - 1;
+    g.nR = g.nRc + 2 * p;
+    g.SR = round_up(g.nRc + 1, 4);
+    g.Se = g.Dc;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_wL = take((size_t)win * g.Tx * 4);
+    g.off_wR = take((size_t)win * g.SR * 4);
+    g.off_e = take((size_t)g.nL * g.Se);
+    g.off_labL = take((size_t)g.nL * 16);
+    g.off_labR = take((size_t)g.nR * 16);
+    g.off_bgrL = take((size_t)g.nL * 4);
+    g.off_bgrR = take((size_t)g.nR * 4);
+    g.off_bestL = take((size_t)g.Tx * 8);
+    g.off_bestR = take((size_t)(g.nRc + 1) * 8);
+    g.lds_bytes = (int)off;
+    return off <= limit;
+}
+
+// Pick (columns per tile, disparities per chunk) minimising estimated VALU work per
+// useful tap: 4 ops/tap in the main loop, ~12 per support weight, ~3 per e byte.
+int asw_choose_geometry(AswGeom &best, int W, int win, int nD)
+{
+    double best_cost = 1e300;
+    bool found = false;
+    const int p = win / 2;
+    for (int nch = 1; nch <= nD; ++nch) {
+        const int per = (nD + nch - 1) / nch;
+        const int DG = round_up(per, ASW_RD) / ASW_RD;
+        if (DG > 64) continue;
+        const int nch_eff = (nD + DG * ASW_RD - 1) / (DG * ASW_RD);
+        if (nch_eff != nch) continue;
+        const int xg_cap = std::min({ASW_MAX_THREADS / DG, 32, (W + ASW_RX - 1) / ASW_RX});
+        for (int pass = 0; pass < 2; ++pass) {
+            const size_t limit = pass == 0 ? 80 * 1024 : 160 * 1024;
+            for (int XG = xg_cap; XG >= 1; --XG) {
+                AswGeom g;
+                if (!asw_layout(g, win, XG, DG, limit)) continue;
+                g.nchunks = nch;
+                const double taps = (double)g.Tx * g.Dc * win;                     // per window row
+                const double work = taps * 4.0 + 12.0 * win * (g.Tx + g.nRc) + 3.0 * g.nL * g.Dc;
+                const double lanes = (double)g.threads / (XG * DG);
+                const double xtiles = (double)((W + g.Tx - 1) / g.Tx) * g.Tx / W;
+                const double useful = (double)g.Tx * win * ((double)nD / nch);
+                double c = work / useful * lanes * xtiles * (pass == 0 ? 1.0 : 1.25);
+                if (g.threads < 128) c *= 1.2;
+                if (c < best_cost) { best_cost = c; best = g; found = true; }
+            }
+        }
+        if (DG <= 2) break;
+    }
+    (void)p;
+    return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no ASW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
+}
+
+int upload_prox(Ctx &c, int win, double gammaP, hipStream_t s)
+{
+    if (c.prox_win == win && c.prox_gammaP == gammaP) return SSAMD_OK;
+    const int p = win / 2;
+    std::vector<float> t((size_t)win * win);
+    for (int i = 0; i < win; ++i)            // _passive.cpp:360-364
+        for (int j = 0; j < win; ++j) {
+            const double di = i - p, dj = j - p;
+            t[(size_t)i * win + j] = (float)std::exp(-std::sqrt(di * di + dj * dj) / gammaP);
+        }
+    int rc = c.prox.reserve(t.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));        // a previous launch may still read the old table
+    HIP_TRY(hipMemcpy(c.prox.ptr, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    c.prox_win = win; c.prox_gammaP = gammaP;
+    return SSAMD_OK;
+}
+
+int launch_lab_records(Ctx &c, const uint8_t *d_img, PixRec *rec, int W, int r0, int r1, hipStream_t s)
+{
+    const long long npix = (long long)(r1 - r0) * W;
+    if (npix <= 0) return SSAMD_OK;
+    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 8);
+    Timed t(c, s, SSAMD_K_LAB);
+    hipLaunchKernelGGL(bgr2lab_records_kernel, dim3(blocks), dim3(256), 0, s, d_img + (size_t)r0 * W * 3,
+                       rec + (size_t)r0 * W, npix);
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_disp, hipStream_t s)
+{
+    if (rows <= 0) return SSAMD_OK;
+    Timed t(c, s, slot);
+    if (lrcheck) {
+        const size_t lds = (((size_t)W * 2 + 15) & ~(size_t)15) + W;
+        hipLaunchKernelGGL(lr_check_fill_kernel, dim3(rows), dim3(256), lds, s, (const u64 *)c.keyL.ptr,
+                           (const u64 *)c.keyR.ptr, d_disp, rows, W);
+    } else {
+        const long long n = (long long)rows * W;
+        const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyL.ptr, d_disp, rows, W);
+    }
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
+                    int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
+                    float *d_costs, hipStream_t s)
+{
+    int rc = check_common(H, W, win, minD, maxD, row0, rows);
+    if (rc) return rc;
+    if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
+    if (rows == 0) return SSAMD_OK;
+    const int p = win / 2, nD = maxD - minD + 1;
+    const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
+
+    if ((rc = c.keyL.reserve(nout * 8))) return rc;
+    if (consistent && (rc = c.keyR.reserve(nout * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+    if (consistent) HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+
+    if (nD >= 1) {
+        if ((rc = c.recL.reserve(npix * sizeof(PixRec)))) return rc;
+        if ((rc = c.recR.reserve(npix * sizeof(PixRec)))) return rc;
+        if ((rc = upload_prox(c, win, gammaP, s))) return rc;
+        const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
+        if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
+        if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
+
+        AswArgs a;
+        if ((rc = asw_choose_geometry(a.g, W, win, nD))) return rc;
+        a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
+        a.prox = (const float *)c.prox.ptr;
+        a.keyL = (u64 *)c.keyL.ptr; a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+        a.costs = d_costs;
+        a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
+        a.kC = (float)(-1.4426950408889634 / gammaC);
+        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, rows, a.g.nchunks), block(a.g.threads);
+        auto kern = d_costs ? asw_aggregate_kernel<true> : asw_aggregate_kernel<false>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.g.lds_bytes));
+        {
+            Timed t(c, s, SSAMD_K_ASW_AGG);
+            hipLaunchKernelGGL(kern, grid, block, a.g.lds_bytes, s, a);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s);
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int ssamd_abi_version(void) { return SSAMD_ABI_VERSION; }
+const char *ssamd_last_error(void) { return g_err.c_str(); }
+
+int ssamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ssamd_kernel_name(int slot)
+{
+    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel", "asw_aggregate_kernel", "asw finalize (wta_decode / lr_check_fill)",
+                                               "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)"};
+    return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
+}
+
+int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!out) return fail(SSAMD_EINVAL, "out is NULL");
+    int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
+    if (rc) return rc;
+    const int nD = maxDisparity - minDisparity + 1;
+    if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
+    AswGeom g;
+    if ((rc = asw_choose_geometry(g, width, winSize, nD))) return rc;
+    out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
+    out[5] = (width + g.Tx - 1) / g.Tx; out[6] = rows; out[7] = g.nchunks;
+    return SSAMD_OK;
+}
+
+int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
+                     int16_t *d_disparity, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    Ctx *c;
+    int rc = get_ctx(-1, &c);
+    if (rc) return rc;
+    return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
+                           gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream);
+}
+
+static int asw_host(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, double gammaC,
+                    double gammaP, int consistent, int16_t *disparity, float *costs, int device)
+{
+    if (!img1 || !img2 || (!disparity && !costs)) return fail(SSAMD_EINVAL, "NULL buffer");
+    Ctx *c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if ((rc = check_common(H, W, win, minD, maxD, 0, H))) return rc;
+    const size_t nb = (size_t)H * W * 3, nout = (size_t)H * W;
+    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
+    const size_t ncost = costs ? nout * (size_t)std::max(1, maxD - minD + 1) : 0;
+    if (costs && (rc = c->costs.reserve(ncost * 4))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img1, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, nb, hipMemcpyHostToDevice, s));
+    if (costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
+    rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, H, W, 0, H, win, maxD, minD,
+                         gammaC, gammaP, consistent, (int16_t *)c->disp.ptr, costs ? (float *)c->costs.ptr : nullptr, s);
+    if (rc) return rc;
+    if (disparity) HIP_TRY(hipMemcpyAsync(disparity, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    if (costs) HIP_TRY(hipMemcpyAsync(costs, c->costs.ptr, ncost * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+              int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                    disparity, nullptr, device);
+}
+
+int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, double gammaC, double gammaP, float *costs, int device)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!costs) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (maxDisparity < minDisparity) return fail(SSAMD_EINVAL, "empty disparity range");
+    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, nullptr, costs,
+                    device);
+}
+
+int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!img || !lab || height <= 0 || width <= 0) return fail(SSAMD_EINVAL, "bad argument");
+    Ctx *c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    const size_t npix = (size_t)height * width;
+    if ((rc = c->imgL.reserve(npix * 3)) || (rc = c->lab.reserve(npix * 12))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img, npix * 3, hipMemcpyHostToDevice, s));
+    const int blocks = (int)std::min<size_t>((npix + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(bgr2lab_f32_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t *)c->imgL.ptr,
+                       (float *)c->lab.ptr, (long long)npix);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lab, c->lab.ptr, npix * 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity, int gamma, float fMax, int iterations, int bins,
+                     int16_t *d_disparity, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    (void)d_img1; (void)d_img2; (void)height; (void)width; (void)out_row0; (void)out_rows; (void)winSize;
+    (void)maxDisparity; (void)minDisparity; (void)gamma; (void)fMax; (void)iterations; (void)bins;
+    (void)d_disparity; (void)stream;
+    return fail(SSAMD_ELIMIT, "GSW kernels are not part of this build yet");
+}
+
+int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+              int minDisparity, int gamma, float fMax, int iterations, int bins, int16_t *disparity, int device)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    (void)img1; (void)img2; (void)height; (void)width; (void)winSize; (void)maxDisparity; (void)minDisparity;
+    (void)gamma; (void)fMax; (void)iterations; (void)bins; (void)disparity; (void)device;
+    return fail(SSAMD_ELIMIT, "GSW kernels are not part of this build yet");
+}
+
+int ssamd_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    for (auto &c : g_ctx) c.prof.on = on != 0;
+    return SSAMD_OK;
+}
+
+int ssamd_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    for (auto &c : g_ctx) {
+        if (c.dev < 0) continue;
+        (void)hipSetDevice(c.dev);
+        c.prof.drain();
+        std::fill(c.prof.ms, c.prof.ms + SSAMD_K_COUNT, 0.0);
+        std::fill(c.prof.n, c.prof.n + SSAMD_K_COUNT, 0LL);
+    }
+    return SSAMD_OK;
+}
+
+int ssamd_profile_read(double *ms, long long *launches)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int k = 0; k < SSAMD_K_COUNT; ++k) { if (ms) ms[k] = 0; if (launches) launches[k] = 0; }
+    for (auto &c : g_ctx) {
+        if (c.dev < 0) continue;
+        (void)hipSetDevice(c.dev);
+        c.prof.drain();
+        for (int k = 0; k < SSAMD_K_COUNT; ++k) { if (ms) ms[k] += c.prof.ms[k]; if (launches) launches[k] += c.prof.n[k]; }
+    }
+    (void)hipSetDevice(cur);
+    return SSAMD_OK;
+}
+
+}  // extern "C"

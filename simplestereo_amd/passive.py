@@ -1,0 +1,271 @@
+"""
+passive
+=======
+Passive stereo matchers with the API of ``simplestereo.passive`` (reference
+``simplestereo/passive.py``), executed by hand-written HIP kernels on an AMD
+MI355X through the C ABI of ``libssamd.so`` (``include/ssamd.h``).
+
+    import simplestereo_amd as ss
+    disparity = ss.passive.StereoASW(winSize=35, maxDisparity=64).compute(imgL, imgR)
+
+Same class names, keyword names, defaults, public attributes, return type
+(a fresh ``numpy.int16 [H, W]`` array) and exceptions as the reference:
+
+=====================================  ===========================================
+condition                              exception (reference ``_passive.cpp`` line)
+=====================================  ===========================================
+img not an ndarray / int arg a float   ``ValueError("Invalid input format!")`` (304, 712)
+image dtype is not uint8               ``TypeError("Wrong type input!")`` (312, 720)
+not [H,W,3] or shapes differ           ``ValueError("Wrong image dimensions!")`` (319, 727)
+winSize even or <= 0                   ``ValueError("winSize must be a positive odd number!")`` (323, 731)
+=====================================  ===========================================
+
+Documented deviations that turn undefined behaviour of the reference into
+defined behaviour: ``img2``'s dtype is checked too (the reference tests ``img1``
+twice, ``_passive.cpp:309``), non-contiguous inputs are made contiguous (the
+reference reads them as if contiguous), negative ``minDisparity`` is rejected
+(out-of-bounds reads in the reference).
+
+Extension (not in the reference): ``compute`` also accepts two CUDA/HIP
+``torch.uint8`` tensors ``[H,W,3]`` already resident in HBM and then returns a
+``torch.int16`` tensor on the same device without any host round trip.
+"""
+import ctypes
+import operator
+
+import numpy as np
+
+from . import _native
+
+__all__ = ["StereoASW", "StereoGSW"]
+
+_INT_MIN, _INT_MAX = -2 ** 31, 2 ** 31 - 1
+
+
+def _c_int(v):
+    """PyArg_ParseTuple 'i': anything with __index__ that fits a C int; floats are refused.
+    Every parse failure surfaces as ValueError("Invalid input format!") (_passive.cpp:304)."""
+    try:
+        i = operator.index(v)
+    except TypeError:
+        raise ValueError("Invalid input format!") from None
+    if not _INT_MIN <= i <= _INT_MAX:
+        raise ValueError("Invalid input format!")
+    return i
+
+
+def _c_double(v):
+    """PyArg_ParseTuple 'd' / 'f': anything float() accepts."""
+    try:
+        return float(v)
+    except (TypeError, ValueError):
+        raise ValueError("Invalid input format!") from None
+
+
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+def _check_pair(img1, img2):
+    """The checks of _passive.cpp:301-321 in the reference's order; returns contiguous arrays."""
+    if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
+        raise ValueError("Invalid input format!")                       # "O!" with PyArray_Type
+    if img1.dtype != np.uint8 or img2.dtype != np.uint8:
+        raise TypeError("Wrong type input!")
+    if (img1.ndim != 3 or img2.ndim != 3 or img1.shape[2] != 3 or img2.shape[2] != 3
+            or img1.shape[0] != img2.shape[0] or img1.shape[1] != img2.shape[1]):
+        raise ValueError("Wrong image dimensions!")
+    return np.ascontiguousarray(img1), np.ascontiguousarray(img2)
+
+
+def _check_pair_tensors(t1, t2):
+    import torch
+    if t1.dtype != torch.uint8 or t2.dtype != torch.uint8:
+        raise TypeError("Wrong type input!")
+    if (t1.dim() != 3 or t2.dim() != 3 or t1.shape[2] != 3 or t2.shape[2] != 3
+            or t1.shape[0] != t2.shape[0] or t1.shape[1] != t2.shape[1] or t1.device != t2.device):
+        raise ValueError("Wrong image dimensions!")
+    return t1.contiguous(), t2.contiguous()
+
+
+def _raise_native(e):
+    if e.code == -1:
+        raise ValueError(e.message) from None
+    raise e
+
+
+class StereoASW():
+    """
+    Adaptive Support-Weight stereo matching (K. Yoon, I. Kweon, 2006) -- drop-in for
+    ``simplestereo.passive.StereoASW`` (reference ``passive.py:16-92``).
+
+    Parameters
+    ----------
+    winSize : int
+        Side of the square window. Must be an odd positive number. Default is 35.
+    maxDisparity: int
+        Maximum accepted disparity. Default is 16.
+    minDisparity: int
+        Minimum valid disparity, usually set to zero. Default is 0.
+    gammaC : float
+        Color parameter. If increased, it increases the color influence. Default is 5.
+    gammaP : float
+        Proximity parameter. If increased, it increases the proximity influence. Default is 17.5.
+    consistent : bool
+        If True the disparity is also computed with the right image as reference; any
+        non-corresponding value is invalidated (occluded) and filled with the nearest
+        minimum left-right non-occluded disparity.  On the GPU this costs one extra
+        reduction, not a second aggregation (the aggregated cost is symmetric).
+    """
+
+    def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False):
+        if not (winSize > 0 and winSize % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        self.winSize = winSize
+        self.maxDisparity = maxDisparity
+        self.minDisparity = minDisparity
+        self.gammaC = gammaC
+        self.gammaP = gammaP
+        self.consistent = consistent
+
+    def _params(self):
+        win, maxd, mind = _c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity)
+        gc, gp = _c_double(self.gammaC), _c_double(self.gammaP)
+        return win, maxd, mind, gc, gp, 1 if self.consistent else 0
+
+    def compute(self, img1, img2):
+        """
+        Compute disparity map for BGR images.
+
+        Parameters
+        ----------
+        img1, img2 : numpy.ndarray (uint8, [H,W,3], BGR as returned by cv2.imread)
+            Left and right rectified images of the same shape.
+
+        Returns
+        -------
+        numpy.ndarray (np.int16)
+            A disparity map of the same width and height of the images.
+        """
+        if _is_device_tensor(img1) and _is_device_tensor(img2):
+            return self._compute_device(img1, img2)
+        lib = _native.lib()
+        if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
+            raise ValueError("Invalid input format!")
+        win, maxd, mind, gc, gp, cons = self._params()
+        a, b = _check_pair(img1, img2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = a.shape[:2]
+        out = np.empty((H, W), np.int16)
+        try:
+            _native.check(lib.ssamd_asw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
+                                        out.ctypes.data, -1))
+        except _native.NativeError as e:
+            _raise_native(e)
+        return out
+
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None):
+        """Operands already in HBM (torch tensors): returns a torch.int16 tensor on the device.
+        Rows [out_row0, out_row0+out_rows) of the given (sub-)image are matched."""
+        import torch
+        lib = _native.lib()
+        win, maxd, mind, gc, gp, cons = self._params()
+        a, b = _check_pair_tensors(t1, t2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = int(a.shape[0]), int(a.shape[1])
+        rows = H - out_row0 if out_rows is None else int(out_rows)
+        out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            try:
+                _native.check(lib.ssamd_asw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
+                                                   maxd, mind, gc, gp, cons, out.data_ptr(),
+                                                   ctypes.c_void_p(stream)))
+            except _native.NativeError as e:
+                _raise_native(e)
+        return out
+
+
+class StereoGSW():
+    """
+    Geodesic Support-Weight matching as implemented by the reference
+    (``simplestereo.passive.StereoGSW``, reference ``passive.py:99-158``): left- and
+    right-referenced winner-take-all on geodesically weighted, truncated colour
+    distances, left-right check and occlusion filling (always on).
+
+    Parameters
+    ----------
+    winSize : int, optional
+        Side of the square window. Must be an odd positive number. Default is 11.
+    maxDisparity: int, optional
+        Maximum accepted disparity. Default is 16.
+    minDisparity: int, optional
+        Minimum valid disparity, usually set to zero. Default is 0.
+    gamma : int, optional
+        Gamma parameter (must be an int, like the reference's "i" format). Default is 10.
+    fMax : int or float, optional
+        Color difference is capped to this value. Default is 120.
+    iterations : int, optional
+        Number of iteration for geodesic distances estimation. Default is 3.
+    bins : int, optional
+        Accepted and unused (the reference never reads it). Default is 20.
+    """
+
+    def __init__(self, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20):
+        if not (winSize > 0 and winSize % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        self.winSize = winSize
+        self.gamma = gamma
+        self.maxDisparity = maxDisparity
+        self.minDisparity = minDisparity
+        self.fMax = fMax
+        self.iterations = iterations
+        self.bins = bins
+
+    def _params(self):
+        return (_c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity), _c_int(self.gamma),
+                _c_double(self.fMax), _c_int(self.iterations), _c_int(self.bins))
+
+    def compute(self, img1, img2):
+        """
+        Compute disparity map for 3-color channel images.
+        """
+        if _is_device_tensor(img1) and _is_device_tensor(img2):
+            return self._compute_device(img1, img2)
+        lib = _native.lib()
+        if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
+            raise ValueError("Invalid input format!")
+        win, maxd, mind, gamma, fmax, it, bins = self._params()
+        a, b = _check_pair(img1, img2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = a.shape[:2]
+        out = np.empty((H, W), np.int16)
+        try:
+            _native.check(lib.ssamd_gsw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gamma, fmax, it, bins,
+                                        out.ctypes.data, -1))
+        except _native.NativeError as e:
+            _raise_native(e)
+        return out
+
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None):
+        import torch
+        lib = _native.lib()
+        win, maxd, mind, gamma, fmax, it, bins = self._params()
+        a, b = _check_pair_tensors(t1, t2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = int(a.shape[0]), int(a.shape[1])
+        rows = H - out_row0 if out_rows is None else int(out_rows)
+        out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            try:
+                _native.check(lib.ssamd_gsw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
+                                                   maxd, mind, gamma, fmax, it, bins, out.data_ptr(),
+                                                   ctypes.c_void_p(stream)))
+            except _native.NativeError as e:
+                _raise_native(e)
+        return out

@@ -1,0 +1,134 @@
+"""Row-strip partitioning of one stereo pair across the GPUs of a node.
+
+Output row y of ASW/GSW depends only on input rows y-pad .. y+pad of both images
+(pad = winSize // 2; reference ``_passive.cpp:38-40, 60-62``) and the left-right
+check / occlusion fill only touches row y (``:251-285``); the reference already
+treats rows as independent jobs (``:372-374``).  So the image is cut into
+contiguous strips of rows, one per rank (one process per GPU); each rank needs
+``pad`` extra *input* rows above and below its strip -- the halo -- which it
+receives from the ranks owning them, point-to-point over RCCL/xGMI
+(``torch.distributed`` backend ``nccl``; ``gloo`` on CPU for the tests).  No
+intermediate data is exchanged: a strip that carries its full halo reproduces
+the whole-image rows bit-exactly, because the kernels treat the sub-image border
+as the image border only where it *is* the image border.
+
+    own   = rows [r0, r1) of the image         (resident on this rank)
+    sub   = rows [h0, h1) = own + halos         (after exchange_halos)
+    out   = matcher rows [r0-h0, r1-h0) of sub  (strip of the disparity map)
+
+The halo exchange is one batched group of isend/irecv (ncclGroupStart/End under
+the hood), at most a few messages of pad*W*3 bytes per neighbour and image; the
+strips of the result are collected with one all_gather on equal-padded strips.
+"""
+import numpy as np
+
+__all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip"]
+
+
+def strip_bounds(height, world_size, rank):
+    """Rows [r0, r1) owned by `rank`: contiguous, sizes differ by at most one row."""
+    base, extra = divmod(int(height), int(world_size))
+    r0 = rank * base + min(rank, extra)
+    r1 = r0 + base + (1 if rank < extra else 0)
+    return r0, r1
+
+
+def halo_bounds(height, r0, r1, pad):
+    """Input rows [h0, h1) needed to compute output rows [r0, r1)."""
+    if r1 <= r0:
+        return r0, r0
+    return max(0, r0 - pad), min(int(height), r1 + pad)
+
+
+def transfer_plan(height, world_size, pad):
+    """All point-to-point messages of one halo exchange.
+
+    Returns a list of ``(src_rank, dst_rank, row_begin, row_end)``: global rows
+    [row_begin,row_end) owned by src that dst needs as halo.  Deterministic and
+    identical on every rank, so sends and receives pair up without negotiation.
+    Handles strips thinner than the halo (rows then come from several ranks).
+    """
+    own = [strip_bounds(height, world_size, r) for r in range(world_size)]
+    plan = []
+    for dst in range(world_size):
+        r0, r1 = own[dst]
+        h0, h1 = halo_bounds(height, r0, r1, pad)
+        for src in range(world_size):
+            if src == dst:
+                continue
+            s0, s1 = own[src]
+            for lo, hi in ((max(h0, s0), min(r0, s1)), (max(r1, s0), min(h1, s1))):
+                if hi > lo:
+                    plan.append((src, dst, lo, hi))
+    return plan
+
+
+def exchange_halos(own_left, own_right, height, pad, rank, world_size, group=None):
+    """Assemble this rank's sub-image (strip + halo rows) of both images.
+
+    own_left / own_right: torch uint8 tensors [r1-r0, W, 3] holding the rows this
+    rank owns (CUDA tensors with the nccl backend, CPU tensors with gloo).
+    Returns ``(sub_left, sub_right, out_row0, out_rows)``.
+    """
+    import torch
+    import torch.distributed as dist
+    r0, r1 = strip_bounds(height, world_size, rank)
+    h0, h1 = halo_bounds(height, r0, r1, pad)
+    W = own_left.shape[1]
+    assert own_left.shape[0] == r1 - r0 and own_right.shape == own_left.shape
+    subs = []
+    for own in (own_left, own_right):
+        sub = torch.empty((h1 - h0, W, 3), dtype=own.dtype, device=own.device)
+        sub[r0 - h0:r1 - h0] = own
+        subs.append(sub)
+    if world_size > 1:
+        ops, keep = [], []
+        for src, dst, lo, hi in transfer_plan(height, world_size, pad):
+            for own, sub in zip((own_left, own_right), subs):
+                if src == rank:
+                    buf = own[lo - r0:hi - r0].contiguous()
+                    keep.append(buf)
+                    ops.append(dist.P2POp(dist.isend, buf, dst, group=group))
+                elif dst == rank:
+                    ops.append(dist.P2POp(dist.irecv, sub[lo - h0:hi - h0], src, group=group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+    return subs[0], subs[1], r0 - h0, r1 - r0
+
+
+def gather_strips(strip_disparity, height, rank, world_size, group=None):
+    """All-gather the per-rank disparity strips into the full [height, W] map (on every rank)."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return strip_disparity
+    W = strip_disparity.shape[1]
+    rows_max = -(-int(height) // world_size)
+    padded = torch.zeros((rows_max, W), dtype=strip_disparity.dtype, device=strip_disparity.device)
+    padded[:strip_disparity.shape[0]] = strip_disparity
+    parts = [torch.empty_like(padded) for _ in range(world_size)]
+    dist.all_gather(parts, padded, group=group)
+    out = torch.empty((int(height), W), dtype=strip_disparity.dtype, device=strip_disparity.device)
+    for r in range(world_size):
+        r0, r1 = strip_bounds(height, world_size, r)
+        out[r0:r1] = parts[r][:r1 - r0]
+    return out
+
+
+def match_strip(matcher, own_left, own_right, height, rank, world_size, group=None, gather=True):
+    """One distributed `compute`: halo exchange -> kernels on the strip -> (optional) gather.
+
+    matcher: a ``StereoASW`` / ``StereoGSW`` instance; the tensors must be device
+    tensors (the kernels run on the tensors' GPU on the current stream).
+    """
+    pad = int(matcher.winSize) // 2
+    subL, subR, out_row0, out_rows = exchange_halos(own_left, own_right, height, pad, rank, world_size, group)
+    strip = matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows)
+    return gather_strips(strip, height, rank, world_size, group) if gather else strip
+
+
+def split_rows(image, world_size):
+    """Host-side helper: the list of row strips of a numpy image (views)."""
+    H = image.shape[0]
+    return [np.ascontiguousarray(image[slice(*strip_bounds(H, world_size, r))]) for r in range(world_size)]
