@@ -32,12 +32,13 @@ namespace ssamd {
 
 static constexpr int ASW_RX = 4;      // columns per thread
 static constexpr int ASW_RD = 8;      // disparities per thread
-static constexpr int ASW_MAX_THREADS = 512;
+static constexpr int ASW_MAX_THREADS = 768;
 
 struct AswGeom {
     int Tx, XG, DG, Dc, nchunks, threads;
-    int nL, nR, nRc, SR, Se;
-    int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR;
+    int nL, nR, nRc, SR, Se, emask;
+    int wseg, wlen;              // weight build: tap columns split in wseg segments of wlen
+    int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen;
     int lds_bytes;
 };
 
@@ -52,30 +53,76 @@ struct AswArgs {
     AswGeom g;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Matching-cost cap of the reference (std::min(40, ...), _passive.cpp:77).
+static constexpr float ASW_TAD_CAP = 40.0f;
+
+// Each (x,d) pair accumulates TWO weighted sums over the window taps,
+//     N  = sum w * e            and      S' = sum w * (40 - e),      w = wL*wR,
+// instead of the reference's (sum w*e, sum w).  N + S' = 40 * sum w, so
+//     cost = 40 N / (N + S')     and     40 - cost = 40 S' / (N + S').
+// fp32 keeps full RELATIVE precision on whichever of N, S' is small: costs near 0
+// and costs near the truncation value 40 (where the reference's candidates differ
+// by 1e-6 and less: occlusions, textureless areas) are both resolved, which a
+// fp32 (sum w*e)/(sum w) cannot do.  The WTA key is built from whichever form is
+// accurate (asw_cost_key).
+__device__ __forceinline__ v2f asw_epair(uint32_t word, int byte)
+{
+    const float e = (float)((word >> (8 * byte)) & 0xffu);   // v_cvt_f32_ubyteN
+    return v2f{e, ASW_TAD_CAP - e};
+}
+
+__device__ __forceinline__ void asw_row_pairs(v2f (&row)[ASW_RD], const uint2 packed)
+{
+#pragma unroll
+    for (int di = 0; di < ASW_RD; ++di) row[di] = asw_epair(di < 4 ? packed.x : packed.y, di & 3);
+}
+
 // 32 taps of one tap column for the thread's 4x8 register tile.
-// r0..r3: the e rows (8 packed bytes = 8 disparities) for the thread's 4 columns.
-__device__ __forceinline__ void asw_taps(float (&cost)[ASW_RX][ASW_RD], float (&tot)[ASW_RX][ASW_RD],
-                                         const float4 wl4, const float4 wa, const float4 wb, const float4 wc,
-                                         const uint2 r0, const uint2 r1, const uint2 r2, const uint2 r3)
+// r0..r3: (e, 40-e) pairs of the e rows of the thread's 4 columns at this tap column.
+__device__ __forceinline__ void asw_taps(v2f (&acc)[ASW_RX][ASW_RD], const float4 wl4, const float4 wa,
+                                         const float4 wb, const float4 wc, const v2f (&r0)[ASW_RD],
+                                         const v2f (&r1)[ASW_RD], const v2f (&r2)[ASW_RD], const v2f (&r3)[ASW_RD])
 {
     const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
     const float wr[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
-    const uint2 rows[4] = {r0, r1, r2, r3};
 #pragma unroll
-    for (int xi = 0; xi < ASW_RX; ++xi) {
-#pragma unroll
-        for (int di = 0; di < ASW_RD; ++di) {
-            const uint32_t word = di < 4 ? rows[xi].x : rows[xi].y;
-            const float e = (float)((word >> (8 * (di & 3))) & 0xffu);   // v_cvt_f32_ubyteN
-            const float w = wl[xi] * wr[xi - di + 7];
-            cost[xi][di] = fmaf(w, e, cost[xi][di]);
-            tot[xi][di] += w;
-        }
+    for (int di = 0; di < ASW_RD; ++di) {
+        const float w0 = wl[0] * wr[7 - di], w1 = wl[1] * wr[8 - di], w2 = wl[2] * wr[9 - di], w3 = wl[3] * wr[10 - di];
+        acc[0][di] = __builtin_elementwise_fma(v2f{w0, w0}, r0[di], acc[0][di]);
+        acc[1][di] = __builtin_elementwise_fma(v2f{w1, w1}, r1[di], acc[1][di]);
+        acc[2][di] = __builtin_elementwise_fma(v2f{w2, w2}, r2[di], acc[2][di]);
+        acc[3][di] = __builtin_elementwise_fma(v2f{w3, w3}, r3[di], acc[3][di]);
     }
 }
 
+// Order-preserving 32-bit image of the aggregated cost of one (x,d) pair, and the
+// cost itself.  cost <= 20: bits(cost); cost > 20: 0xC0000000 - bits(40 - cost), which
+// is > bits(20.0f) and decreasing in (40 - cost): a monotone map of the cost that keeps
+// the resolution of the accurate operand.
+__device__ __forceinline__ uint32_t asw_cost_key(const v2f acc, float &cost)
+{
+    const float n = acc.x, s = acc.y, t40 = n + s;
+    if (n <= s) {
+        cost = ASW_TAD_CAP * n / t40;
+        return __float_as_uint(cost);
+    }
+    const float inv = ASW_TAD_CAP * s / t40;
+    cost = ASW_TAD_CAP - inv;
+    return 0xC0000000u - __float_as_uint(inv);
+}
+
+// e tile addressing: rows of Se bytes (Se = 8 * power of two >= Dc), the 8-byte slot of
+// disparity group dg in row ul is XOR-swizzled with (ul >> 2) so that the 32 lanes of a
+// ds_read_b64 group (consecutive xg, rows 4 apart) hit 32 distinct bank pairs.
+__device__ __forceinline__ int asw_e_offset(int ul, int slot, int Se, int emask)
+{
+    return ul * Se + ((slot ^ ((ul >> 2) & emask)) << 3);
+}
+
 template <bool WITH_COSTS>
-__global__ __launch_bounds__(ASW_MAX_THREADS, 4) void asw_aggregate_kernel(const AswArgs A)
+__global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const AswArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AswGeom &g = A.g;
@@ -88,10 +135,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 4) void asw_aggregate_kernel(const
     uint32_t *const bgrR = reinterpret_cast<uint32_t *>(smem + g.off_bgrR);
     u64 *const bestL = reinterpret_cast<u64 *>(smem + g.off_bestL);
     u64 *const bestR = reinterpret_cast<u64 *>(smem + g.off_bestR);
+    float4 *const cenLab = reinterpret_cast<float4 *>(smem + g.off_cen);
 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int W = A.W, win = A.win, p = A.pad;
-    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nR = g.nR, nRc = g.nRc, SR = g.SR, Se = g.Se;
+    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nR = g.nR, nRc = g.nRc, SR = g.SR, Se = g.Se, emask = g.emask;
     const int x0 = blockIdx.x * Tx;
     const int y = A.row0 + blockIdx.y;
     const int dlo = A.minD + blockIdx.z * Dc;
@@ -103,30 +151,42 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 4) void asw_aggregate_kernel(const
     const int xrc_lo = x0 - dhi;       // first right-image window centre of the tile
     const int segR_lo = xrc_lo - p;    // first tap column staged from the right image
 
+    // lanes of a wave run along x (xg fastest): their wL / wR reads are consecutive 16-byte
+    // slots (conflict-free ds_read_b128 for any lane grouping)
     const bool active = tid < g.XG * g.DG;
-    const int dg = tid % g.DG, xg = tid / g.DG;
+    const int xg = tid % g.XG, dg = tid / g.XG;
 
-    float cost[ASW_RX][ASW_RD], tot[ASW_RX][ASW_RD];
+    v2f acc[ASW_RX][ASW_RD];
 #pragma unroll
     for (int a = 0; a < ASW_RX; ++a)
 #pragma unroll
-        for (int b = 0; b < ASW_RD; ++b) { cost[a][b] = 0.f; tot[a][b] = 0.f; }
+        for (int b = 0; b < ASW_RD; ++b) acc[a][b] = v2f{0.f, 0.f};
 
     for (int k = tid; k < Tx; k += nthr) bestL[k] = KEY_NONE;
     for (int k = tid; k <= nRc; k += nthr) bestR[k] = KEY_NONE;
 
+    // window centres (row y) of the tile: left columns x0.., then right columns xrc_lo..
+    for (int c = tid; c < Tx + nRc; c += nthr) {
+        const bool isL = c < Tx;
+        const int ccol = isL ? x0 + c : xrc_lo + (c - Tx);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ccol < (unsigned)W) {
+            const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+            v = make_float4(q.L, q.a, q.b, 1.f);
+        }
+        cenLab[c] = v;
+    }
     // e-build task walk: task t -> (ul = t % nL, dq = t / nL), advanced incrementally
     const int e_q = nthr / nL, e_r = nthr % nL;
     const int e_ul0 = tid % nL, e_dq0 = tid / nL;
     const int nDq = Dc >> 2;
 
     const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
-    for (int i = i_lo; i < i_hi; ++i) {
-        const int r = y - p + i;
+    // stage the pixels of image row r this tile touches into staging buffer `buf`
+    // (coalesced 16 B loads; columns outside the image become zero records)
+    auto stage_row = [&](int r, int buf) {
         const PixRec *const rowL = A.recL + (size_t)r * W;
         const PixRec *const rowR = A.recR + (size_t)r * W;
-
-        // ---- stage the pixels of image row r this tile touches (coalesced 16 B loads)
         for (int k = tid; k < nL + nR; k += nthr) {
             const bool isL = k < nL;
             const int idx = isL ? k : k - nL;
@@ -135,35 +195,45 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 4) void asw_aggregate_kernel(const
             v.L = v.a = v.b = 0.f;
             v.bgrx = 0u;
             if ((unsigned)col < (unsigned)W) v = (isL ? rowL : rowR)[col];
-            (isL ? labL : labR)[idx] = make_float4(v.L, v.a, v.b, 0.f);
-            (isL ? bgrL : bgrR)[idx] = v.bgrx;
+            (isL ? labL + buf * nL : labR + buf * nR)[idx] = make_float4(v.L, v.a, v.b, 0.f);
+            (isL ? bgrL + buf * nL : bgrR + buf * nR)[idx] = v.bgrx;
         }
+    };
+    for (int i = i_lo; i < i_hi; ++i) {
+        const int r = y - p + i;
+
+        // ---- pixels of image row r were staged into buffer (i & 1) during the previous
+        //      iteration's aggregation (prologue for the first row): global latency is hidden
+        float4 *const labLc = labL + (i & 1) * nL, *const labRc = labR + (i & 1) * nR;
+        uint32_t *const bgrLc = bgrL + (i & 1) * nL, *const bgrRc = bgrR + (i & 1) * nR;
+        if (i == i_lo) stage_row(r, i & 1);
         __syncthreads();   // staged pixels visible; every thread is done with main(i-1)
 
-        // ---- support weights of window row i: one window centre per thread, 'win' taps
-        //      (_passive.cpp:47-50 and 71-74; exp(-dist/gammaC) = exp2(dist*kC))
-        for (int c = tid; c < Tx + nRc; c += nthr) {
-            const bool isL = c < Tx;
-            const int cc = isL ? c : c - Tx;
-            const int ccol = (isL ? x0 : xrc_lo) + cc;
-            const bool cvalid = (unsigned)ccol < (unsigned)W;
-            float cL = 0.f, ca = 0.f, cb = 0.f;
-            if (cvalid) {
-                const PixRec v = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
-                cL = v.L; ca = v.a; cb = v.b;
-            }
-            const float4 *const seg = (isL ? labL : labR) + cc;
-            float *const wout = (isL ? wL : wR) + cc;
-            const int stride = isL ? Tx : SR;
-            const int col0 = ccol - p;
+        // ---- support weights of window row i (_passive.cpp:47-50 and 71-74;
+        //      exp(-dist/gammaC) = exp2(dist*kC)).  Task = (window centre c, segment of the
+        //      tap columns); consecutive lanes take consecutive centres: conflict-free
+        //      ds_read_b128 of the staged pixels and coalesced LDS writes.
+        {
             const float *const prow = A.prox + i * win;
-            for (int j = 0; j < win; ++j) {
-                const float4 t = seg[j];
-                const float dL = t.x - cL, da = t.y - ca, db = t.z - cb;
-                const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
-                float w = prow[j] * __builtin_amdgcn_exp2f(dist * A.kC);
-                if (!cvalid || (unsigned)(col0 + j) >= (unsigned)W) w = 0.f;   // tap outside the image
-                wout[j * stride] = w;
+            const int ncen = Tx + nRc;
+            for (int t = tid; t < ncen * g.wseg; t += nthr) {
+                const int sgm = t / ncen, c = t - sgm * ncen;
+                const bool isL = c < Tx;
+                const int cc = isL ? c : c - Tx;
+                const float4 cen = cenLab[c];                      // centre pixel (row y); .w = inside image
+                const float4 *const seg = (isL ? labLc : labRc) + cc;
+                float *const wout = (isL ? wL : wR) + cc;
+                const int stride = isL ? Tx : SR;
+                const int col0 = (isL ? x0 : xrc_lo) + cc - p;
+                const int j1 = min(win, (sgm + 1) * g.wlen);
+                for (int j = sgm * g.wlen; j < j1; ++j) {
+                    const float4 tp = seg[j];
+                    const float dL = tp.x - cen.x, da = tp.y - cen.y, db = tp.z - cen.z;
+                    const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
+                    float w = prow[j] * __builtin_amdgcn_exp2f(dist * A.kC);
+                    if (cen.w == 0.f || (unsigned)(col0 + j) >= (unsigned)W) w = 0.f;   // outside the image
+                    wout[j * stride] = w;
+                }
             }
         }
 
@@ -172,35 +242,39 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 4) void asw_aggregate_kernel(const
         {
             int ul = e_ul0, dq = e_dq0;
             while (dq < nDq) {
-                const uint32_t lp = bgrL[ul];
+                const uint32_t lp = bgrLc[ul];
                 const int rbase = ul + (Dc - 1) - 4 * dq;     // index of R[u-d] for d = dlo+4dq
                 uint32_t packed = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t s = min(__builtin_amdgcn_sad_u8(lp, bgrR[rbase - k], 0u), 40u);
+                    const uint32_t s = min(__builtin_amdgcn_sad_u8(lp, bgrRc[rbase - k], 0u), 40u);
                     packed |= s << (8 * k);
                 }
-                *reinterpret_cast<uint32_t *>(eT + ul * Se + 4 * dq) = packed;
+                *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, dq >> 1, Se, emask) + 4 * (dq & 1)) = packed;
                 ul += e_r; dq += e_q;
                 if (ul >= nL) { ul -= nL; ++dq; }
             }
         }
         __syncthreads();   // wL, wR, e ready
+        if (i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
 
         // ---- aggregation over the tap columns j of this window row
         if (active) {
             const float *wLp = wL + ASW_RX * xg;
             const float *wRp = wR + (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD);
-            const unsigned char *ep = eT + (ASW_RX * xg) * Se + ASW_RD * dg;
-#define SSAMD_E(n) (*reinterpret_cast<const uint2 *>(ep + (n) * Se))
+            const int ul0 = ASW_RX * xg;
+#define SSAMD_E(n) (*reinterpret_cast<const uint2 *>(eT + asw_e_offset(ul0 + (n), dg, Se, emask)))
 #define SSAMD_W4(ptr, off) (*reinterpret_cast<const float4 *>((ptr) + (off)))
 #define SSAMD_STEP(j, ra, rb, rc, rd)                                                           \
     if ((j) < win) {                                                                            \
-        rd = SSAMD_E((j) + 3);                                                                  \
-        asw_taps(cost, tot, SSAMD_W4(wLp, (j) * Tx), SSAMD_W4(wRp, (j) * SR),                   \
+        asw_row_pairs(rd, SSAMD_E((j) + 3));                                                    \
+        asw_taps(acc, SSAMD_W4(wLp, (j) * Tx), SSAMD_W4(wRp, (j) * SR),                         \
                  SSAMD_W4(wRp, (j) * SR + 4), SSAMD_W4(wRp, (j) * SR + 8), ra, rb, rc, rd);     \
     }
-            uint2 e0 = SSAMD_E(0), e1 = SSAMD_E(1), e2 = SSAMD_E(2), e3;
+            v2f e0[ASW_RD], e1[ASW_RD], e2[ASW_RD], e3[ASW_RD];
+            asw_row_pairs(e0, SSAMD_E(0));
+            asw_row_pairs(e1, SSAMD_E(1));
+            asw_row_pairs(e2, SSAMD_E(2));
             for (int j0 = 0; j0 < win; j0 += 4) {
                 SSAMD_STEP(j0, e0, e1, e2, e3)
                 SSAMD_STEP(j0 + 1, e1, e2, e3, e0)
@@ -227,9 +301,10 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 4) void asw_aggregate_kernel(const
                 const int d = dlo + ASW_RD * dg + di;
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
                 if (valid) {
-                    const float c = cost[xi][di] / tot[xi][di];
-                    bl = min(bl, make_key(c, (uint32_t)d));
-                    diag[xi - di + 7] = min(diag[xi - di + 7], make_key(c, (uint32_t)x));
+                    float c;
+                    const u64 hi = (u64)asw_cost_key(acc[xi][di], c) << 32;
+                    bl = min(bl, hi | (u64)(uint32_t)d);
+                    diag[xi - di + 7] = min(diag[xi - di + 7], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
                         A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
                 }

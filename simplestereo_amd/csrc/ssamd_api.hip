@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -169,55 +170,89 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     g.nRc = g.Tx + g.Dc - 1;
     g.nR = g.nRc + 2 * p;
     g.SR = round_up(g.nRc + 1, 4);
-    g.Se = g.Dc;
+    int P = 8;                                  // 8-byte slots per e row: power of two >= DG
+    while (P < DG) P <<= 1;
+    g.Se = 8 * P;
+    g.emask = std::min(P, 32) - 1;
+    // weight build balance: (centres x segments) tasks over the workgroup's threads
+    {
+        const int ncen = g.Tx + g.nRc;
+        int best_cost = 1 << 30;
+        for (int ns = 1; ns <= win && ns <= 8; ++ns) {
+            const int len = (win + ns - 1) / ns, rounds = (ncen * ns + g.threads - 1) / g.threads;
+            const int cost = rounds * (len + 2);
+            if (cost < best_cost) { best_cost = cost; g.wseg = ns; g.wlen = len; }
+        }
+    }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
     g.off_wL = take((size_t)win * g.Tx * 4);
     g.off_wR = take((size_t)win * g.SR * 4);
     g.off_e = take((size_t)g.nL * g.Se);
-    g.off_labL = take((size_t)g.nL * 16);
-    g.off_labR = take((size_t)g.nR * 16);
-    g.off_bgrL = take((size_t)g.nL * 4);
-    g.off_bgrR = take((size_t)g.nR * 4);
+    g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
+    g.off_labR = take((size_t)g.nR * 16 * 2);
+    g.off_bgrL = take((size_t)g.nL * 4 * 2);
+    g.off_bgrR = take((size_t)g.nR * 4 * 2);
     g.off_bestL = take((size_t)g.Tx * 8);
     g.off_bestR = take((size_t)(g.nRc + 1) * 8);
+    g.off_cen = take((size_t)(g.Tx + g.nRc) * 16);
     g.lds_bytes = (int)off;
     return off <= limit;
 }
 
-// Pick (columns per tile, disparities per chunk) minimising estimated VALU work per
-// useful tap: 4 ops/tap in the main loop, ~12 per support weight, ~3 per e byte.
-int asw_choose_geometry(AswGeom &best, int W, int win, int nD)
+// Pick the workgroup tile (XG column groups x DG disparity groups, nchunks disparity chunks)
+// with an occupancy-aware cost model calibrated on MI355X (profiles/r01_*):
+//   - the kernel needs 168 VGPRs -> 3 waves per SIMD; a workgroup of w waves puts ceil(w/4)
+//     on each SIMD, so k = min(floor(3 / ceil(w/4)), floor(160 KiB / LDS)) workgroups are
+//     resident per CU.  Measured: 2 x 6-wave groups do NOT co-reside (87 ms), one 12-wave
+//     group does (55 ms) on the 1080p/193/35 workload.
+//   - per window row a thread spends M cycles aggregating and B cycles building weights / e
+//     tiles; B shrinks with the tile (fewer window centres per (x,d) pair).
+//   - padding of the disparity range, idle lanes, partial x tiles and the last partial wave of
+//     workgroups over the 256 CUs are charged as lost throughput.
+int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
-    double best_cost = 1e300;
+    // tuning hook: SSAMD_ASW_GEOM="XG,DG" forces the tile shape (experiments only)
+    if (const char *env = getenv("SSAMD_ASW_GEOM")) {
+        int XG = 0, DG = 0;
+        if (sscanf(env, "%d,%d", &XG, &DG) == 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS) {
+            if (!asw_layout(best, win, XG, DG, 160 * 1024)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
+            best.nchunks = (nD + best.Dc - 1) / best.Dc;
+            return SSAMD_OK;
+        }
+    }
+    const double c_tap = 10.9, c_w = 70.0, c_e = 60.0, c_stage = 40.0;   // cycles (one SIMD lane-slot)
+    double best_score = -1.0;
     bool found = false;
-    const int p = win / 2;
     for (int nch = 1; nch <= nD; ++nch) {
         const int per = (nD + nch - 1) / nch;
         const int DG = round_up(per, ASW_RD) / ASW_RD;
         if (DG > 64) continue;
-        const int nch_eff = (nD + DG * ASW_RD - 1) / (DG * ASW_RD);
-        if (nch_eff != nch) continue;
-        const int xg_cap = std::min({ASW_MAX_THREADS / DG, 32, (W + ASW_RX - 1) / ASW_RX});
-        for (int pass = 0; pass < 2; ++pass) {
-            const size_t limit = pass == 0 ? 80 * 1024 : 160 * 1024;
-            for (int XG = xg_cap; XG >= 1; --XG) {
-                AswGeom g;
-                if (!asw_layout(g, win, XG, DG, limit)) continue;
-                g.nchunks = nch;
-                const double taps = (double)g.Tx * g.Dc * win;                     // per window row
-                const double work = taps * 4.0 + 12.0 * win * (g.Tx + g.nRc) + 3.0 * g.nL * g.Dc;
-                const double lanes = (double)g.threads / (XG * DG);
-                const double xtiles = (double)((W + g.Tx - 1) / g.Tx) * g.Tx / W;
-                const double useful = (double)g.Tx * win * ((double)nD / nch);
-                double c = work / useful * lanes * xtiles * (pass == 0 ? 1.0 : 1.25);
-                if (g.threads < 128) c *= 1.2;
-                if (c < best_cost) { best_cost = c; best = g; found = true; }
-            }
+        if ((nD + DG * ASW_RD - 1) / (DG * ASW_RD) != nch) continue;
+        const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + ASW_RX - 1) / ASW_RX);
+        for (int XG = xg_cap; XG >= 1; --XG) {
+            AswGeom g;
+            if (!asw_layout(g, win, XG, DG, 160 * 1024)) continue;
+            g.nchunks = nch;
+            const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
+            const int k = std::min(3 / per_simd, (160 * 1024) / g.lds_bytes);
+            if (k < 1) continue;
+            const double M = (double)win * ASW_RX * ASW_RD * c_tap;
+            const int ncen = g.Tx + g.nRc;
+            const double B = (double)((ncen * g.wseg + g.threads - 1) / g.threads) * (g.wlen + 2) * c_w +
+                             (double)((g.nL * (g.Dc / 4) + g.threads - 1) / g.threads) * c_e +
+                             (double)((g.nL + g.nR + g.threads - 1) / g.threads) * c_stage;
+            const double d_util = (double)nD / ((double)nch * g.Dc);
+            const int xt = (W + g.Tx - 1) / g.Tx;
+            const double x_util = (double)W / ((double)xt * g.Tx);
+            const double nwg = (double)xt * std::max(rows, 1) * nch, slots = 256.0 * k;
+            const double tail = nwg / (std::ceil(nwg / slots) * slots);
+            const double overlap = k > 1 ? 1.05 : 1.0;             // independent groups hide each other's build phase
+            const double score = (double)k * XG * DG * (M / (M + B)) * d_util * x_util * tail * overlap;
+            if (score > best_score) { best_score = score; best = g; found = true; }
         }
         if (DG <= 2) break;
     }
-    (void)p;
     return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no ASW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
 }
 
@@ -293,7 +328,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
 
         AswArgs a;
-        if ((rc = asw_choose_geometry(a.g, W, win, nD))) return rc;
+        if ((rc = asw_choose_geometry(a.g, W, rows, win, nD))) return rc;
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
         a.prox = (const float *)c.prox.ptr;
         a.keyL = (u64 *)c.keyL.ptr; a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
@@ -343,7 +378,7 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
     const int nD = maxDisparity - minDisparity + 1;
     if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
     AswGeom g;
-    if ((rc = asw_choose_geometry(g, width, winSize, nD))) return rc;
+    if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
     out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
     out[5] = (width + g.Tx - 1) / g.Tx; out[6] = rows; out[7] = g.nchunks;
     return SSAMD_OK;

@@ -104,7 +104,7 @@ def test_geometry_query_is_sane(ss):
         nD = maxd - mind + 1
         assert g["tile_x"] % 4 == 0 and g["chunk_d"] % 8 == 0
         assert g["chunk_d"] * g["n_chunks"] >= nD and g["chunk_d"] * (g["n_chunks"] - 1) < nD
-        assert g["threads"] % 64 == 0 and 64 <= g["threads"] <= 512
+        assert g["threads"] % 64 == 0 and 64 <= g["threads"] <= 768
         assert g["lds_bytes"] <= 160 * 1024
         assert g["grid_x"] * g["tile_x"] >= W
 
