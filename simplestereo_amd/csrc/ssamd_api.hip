@@ -347,6 +347,131 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     return launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s);
 }
 
+
+// ------------------------------------------------------------ GSW
+bool gsw_layout(GswGeom &g, int win, int XG, int DG, size_t limit)
+{
+    const int p = win / 2;
+    g.XG = XG; g.DG = DG;
+    g.Tx = GSW_RX * XG; g.Dc = GSW_RD * DG;
+    g.threads = round_up(XG * DG, 64);
+    g.nL = g.Tx + 2 * p;
+    g.nT = g.nL + g.Dc - 1;
+    int P = 1;
+    while (P < DG) P <<= 1;
+    g.Se = 8 * P;                                  // floats per e row
+    g.emask = std::min(P, 32) - 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_w = take((size_t)win * g.Tx * 4);
+    g.off_e = take((size_t)g.nL * g.Se * 4);
+    g.off_ref = take((size_t)g.nL * 4);
+    g.off_tgt = take((size_t)g.nT * 4);
+    g.off_best = take((size_t)g.Tx * 8);
+    g.lds_bytes = (int)off;
+    return off <= limit;
+}
+
+int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)
+{
+    const double c_tap = 5.3, c_w = 60.0, c_e = 70.0;
+    double best_score = -1.0;
+    bool found = false;
+    for (int nch = 1; nch <= nD; ++nch) {
+        const int per = (nD + nch - 1) / nch;
+        const int DG = round_up(per, GSW_RD) / GSW_RD;
+        if (DG > 64) continue;
+        if ((nD + DG * GSW_RD - 1) / (DG * GSW_RD) != nch) continue;
+        const int xg_cap = std::min(GSW_MAX_THREADS / DG, (W + GSW_RX - 1) / GSW_RX);
+        for (int XG = xg_cap; XG >= 1; --XG) {
+            GswGeom g;
+            if (!gsw_layout(g, win, XG, DG, 160 * 1024)) continue;
+            g.nchunks = nch;
+            const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
+            const int k = std::min({4 / per_simd, (160 * 1024) / g.lds_bytes, 8});   // 98 VGPRs -> 4 waves per SIMD
+            if (k < 1) continue;
+            const double M = (double)win * GSW_RX * GSW_RD * c_tap;
+            const double B = (double)((g.Tx * win + g.threads - 1) / g.threads) * c_w +
+                             (double)((g.nL * g.Dc + g.threads - 1) / g.threads) * c_e;
+            const double d_util = (double)nD / ((double)nch * g.Dc);
+            const int xt = (W + g.Tx - 1) / g.Tx;
+            const double x_util = (double)W / ((double)xt * g.Tx);
+            const double nwg = (double)xt * std::max(rows, 1) * nch, slots = 256.0 * k;
+            const double tail = nwg / (std::ceil(nwg / slots) * slots);
+            const double score = (double)k * XG * DG * (M / (M + B)) * d_util * x_util * tail;
+            if (score > best_score) { best_score = score; best = g; found = true; }
+        }
+        if (DG <= 1) break;
+    }
+    return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no GSW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
+}
+
+// support weight as a function of the integer squared colour distance, in the reference's
+// arithmetic: fl32 distance (sqrt in double), float division by gamma, float exp (_passive.cpp:457-463, 495)
+int upload_gsw_table(Ctx &c, int gamma, hipStream_t s)
+{
+    if (c.gsw_gamma == gamma && c.gswTab.ptr) return SSAMD_OK;
+    std::vector<float> tab(GSW_TAB_SIZE);
+    for (int v = 0; v < GSW_TAB_SIZE; ++v) {
+        const float dist = (float)(0.0f + std::sqrt((double)v));
+        tab[v] = expf(-dist / gamma);
+    }
+    int rc = c.gswTab.reserve(tab.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(c.gswTab.ptr, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    c.gsw_gamma = gamma;
+    return SSAMD_OK;
+}
+
+int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win, int maxD,
+                    int minD, int gamma, float fMax, int iterations, int16_t *d_disp, hipStream_t s)
+{
+    int rc = check_common(H, W, win, minD, maxD, row0, rows);
+    if (rc) return rc;
+    if (gamma == 0) return fail(SSAMD_EINVAL, "gamma must be non-zero");
+    if (rows == 0) return SSAMD_OK;
+    const int p = win / 2, nD = maxD - minD + 1;
+    const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
+    if ((rc = c.keyL.reserve(nout * 8)) || (rc = c.keyR.reserve(nout * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+    HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+    if (nD >= 1) {
+        // packed pixels live in the (larger) ASW record buffers: 4 B/pixel
+        if ((rc = c.recL.reserve(npix * 4)) || (rc = c.recR.reserve(npix * 4))) return rc;
+        if ((rc = upload_gsw_table(c, gamma, s))) return rc;
+        const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
+        const long long np = (long long)(r1 - r0) * W;
+        const int blocks = (int)std::min<long long>((np + 255) / 256, 256 * 8);
+        {
+            Timed t(c, s, SSAMD_K_LAB);
+            hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3,
+                               (uint32_t *)c.recL.ptr + (size_t)r0 * W, np);
+            hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dR + (size_t)r0 * W * 3,
+                               (uint32_t *)c.recR.ptr + (size_t)r0 * W, np);
+            HIP_TRY(hipGetLastError());
+        }
+        GswArgs a;
+        if ((rc = gsw_choose_geometry(a.g, W, rows, win, nD))) return rc;
+        a.tab = (const float *)c.gswTab.ptr;
+        a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
+        a.iterations = iterations; a.fMax = fMax;
+        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, rows, a.g.nchunks), block(a.g.threads);
+        HIP_TRY(hipFuncSetAttribute((const void *)gsw_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    a.g.lds_bytes));
+        for (int pass = 0; pass < 2; ++pass) {
+            a.right = pass;
+            a.ref = (const uint32_t *)(pass ? c.recR.ptr : c.recL.ptr);
+            a.tgt = (const uint32_t *)(pass ? c.recL.ptr : c.recR.ptr);
+            a.key = (u64 *)(pass ? c.keyR.ptr : c.keyL.ptr);
+            Timed t(c, s, SSAMD_K_GSW_AGG);
+            hipLaunchKernelGGL(gsw_aggregate_kernel, grid, block, a.g.lds_bytes, s, a);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return launch_finalize(c, SSAMD_K_GSW_FIN, true, rows, W, d_disp, s);   // consistency is unconditional in GSW
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -466,19 +591,36 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int16_t *d_disparity, void *stream)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
-    (void)d_img1; (void)d_img2; (void)height; (void)width; (void)out_row0; (void)out_rows; (void)winSize;
-    (void)maxDisparity; (void)minDisparity; (void)gamma; (void)fMax; (void)iterations; (void)bins;
-    (void)d_disparity; (void)stream;
-    return fail(SSAMD_ELIMIT, "GSW kernels are not part of this build yet");
+    (void)bins;                       // never read by the reference either (_passive.cpp:410)
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    Ctx *c;
+    int rc = get_ctx(-1, &c);
+    if (rc) return rc;
+    return gsw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
+                           gamma, fMax, iterations, d_disparity, (hipStream_t)stream);
 }
 
 int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
               int minDisparity, int gamma, float fMax, int iterations, int bins, int16_t *disparity, int device)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
-    (void)img1; (void)img2; (void)height; (void)width; (void)winSize; (void)maxDisparity; (void)minDisparity;
-    (void)gamma; (void)fMax; (void)iterations; (void)bins; (void)disparity; (void)device;
-    return fail(SSAMD_ELIMIT, "GSW kernels are not part of this build yet");
+    (void)bins;
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    Ctx *c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if ((rc = check_common(height, width, winSize, minDisparity, maxDisparity, 0, height))) return rc;
+    const size_t nb = (size_t)height * width * 3, nout = (size_t)height * width;
+    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img1, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, nb, hipMemcpyHostToDevice, s));
+    rc = gsw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, height, width, 0, height,
+                         winSize, maxDisparity, minDisparity, gamma, fMax, iterations, (int16_t *)c->disp.ptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(disparity, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
 }
 
 int ssamd_profile_enable(int on)
