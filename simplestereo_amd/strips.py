@@ -107,12 +107,14 @@ def gather_strips(strip_disparity, height, rank, world_size, group=None):
     rows_max = -(-int(height) // world_size)
     padded = torch.zeros((rows_max, W), dtype=strip_disparity.dtype, device=strip_disparity.device)
     padded[:strip_disparity.shape[0]] = strip_disparity
-    parts = [torch.empty_like(padded) for _ in range(world_size)]
-    dist.all_gather(parts, padded, group=group)
+    # int16 is not a NCCL/RCCL (nor gloo) collective dtype: move the strips as raw bytes
+    wire = padded.view(torch.uint8)
+    parts = [torch.empty_like(wire) for _ in range(world_size)]
+    dist.all_gather(parts, wire, group=group)
     out = torch.empty((int(height), W), dtype=strip_disparity.dtype, device=strip_disparity.device)
     for r in range(world_size):
         r0, r1 = strip_bounds(height, world_size, r)
-        out[r0:r1] = parts[r][:r1 - r0]
+        out[r0:r1] = parts[r].view(strip_disparity.dtype)[:r1 - r0]
     return out
 
 

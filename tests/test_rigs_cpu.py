@@ -1,0 +1,118 @@
+"""RectifiedStereoRig plumbing (reference _rigs.py:341-628), numpy-only restatement.
+JSON layout is pinned by the reference's own example rig files (copied as DATA fixtures:
+tests/golden/rig_example2_rigRect.json = examples/res/2/rigRect.json,
+tests/golden/rig_example1_rig.json = examples/res/1/rig.json).  Pixel values of rectifyImages
+cannot be pinned against OpenCV here (cv2 is absent): self-consistency checks instead."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import simplestereo_amd as ss
+from simplestereo_amd import _rigs
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RIGRECT = os.path.join(G, "rig_example2_rigRect.json")
+RIG = os.path.join(G, "rig_example1_rig.json")
+
+
+def test_stereo_rig_json_round_trip(tmp_path):
+    rig = ss.StereoRig.fromFile(RIG)
+    data = json.load(open(RIG))
+    assert tuple(rig.res1) == tuple(data["res1"]) and rig.intrinsic1.shape == (3, 3) and rig.T.shape == (3, 1)
+    out = tmp_path / "rig.json"
+    rig.save(str(out))
+    back = json.load(open(out))
+    for k in ("res1", "res2", "intrinsic1", "intrinsic2", "R", "distCoeffs1", "distCoeffs2"):
+        assert np.allclose(np.asarray(back[k], float).ravel(), np.asarray(data[k], float).ravel())
+    assert np.allclose(np.asarray(back["T"], float).ravel(), np.asarray(data["T"], float).ravel())
+    assert np.isclose(ss.StereoRig.fromFile(str(out)).getBaseline(), rig.getBaseline())
+
+
+def test_rectified_rig_json_round_trip_and_ctor_forms(tmp_path):
+    rig = ss.RectifiedStereoRig.fromFile(RIGRECT)
+    data = json.load(open(RIGRECT))
+    out = tmp_path / "rr.json"
+    rig.save(str(out))
+    back = json.load(open(out))
+    assert set(back) == set(data)
+    for k in data:
+        assert np.allclose(np.asarray(back[k], float).ravel(), np.asarray(data[k], float).ravel()), k
+    # second constructor form: (Rcommon, H1, H2, StereoRig)
+    base = ss.StereoRig(rig.res1, rig.res2, rig.intrinsic1, rig.intrinsic2, rig.distCoeffs1, rig.distCoeffs2, rig.R, rig.T)
+    rig2 = ss.RectifiedStereoRig(rig.Rcommon, rig.rectHomography1, rig.rectHomography2, base)
+    assert np.allclose(rig2.K1, rig.K1) and np.allclose(rig2.mapx2, rig.mapx2)
+    assert rig.mapx1.dtype == np.float32 and rig.mapx1.shape == (rig.res1[1], rig.res1[0])
+
+
+def test_rectified_projections_share_rows():
+    """after rectification a 3D point projects to the same image row in both cameras"""
+    rig = ss.RectifiedStereoRig.fromFile(RIGRECT)
+    P1, P2 = rig.getRectifiedProjectionMatrices()
+    rng = np.random.default_rng(0)
+    X = np.c_[rng.uniform(-500, 500, 50), rng.uniform(-300, 300, 50), rng.uniform(800, 3000, 50), np.ones(50)]
+    a, b = X.dot(P1.T), X.dot(P2.T)
+    y1, y2 = a[:, 1] / a[:, 2], b[:, 1] / b[:, 2]
+    # the example rig comes from a real calibration: its homographies rectify to ~0.1 px
+    assert np.abs(y1 - y2).max() < 0.25
+    x1, x2 = a[:, 0] / a[:, 2], b[:, 0] / b[:, 2]
+    assert np.all((x1 - x2) * np.sign((x1 - x2)[0]) > 0)        # one-signed disparity
+
+
+def test_maps_agree_with_forward_camera_model():
+    """mapx/mapy (initUndistortRectifyMap restatement) == forward projection of the rectified ray
+    through rotation, distortion and intrinsics; undistortPoints inverts the distortion model"""
+    rig = ss.RectifiedStereoRig.fromFile(RIGRECT)
+    h, w = rig.mapx1.shape
+    for (K, dist, Rr, Knew, mx, my) in ((rig.intrinsic1, rig.distCoeffs1, rig.Rcommon, rig.K1, rig.mapx1, rig.mapy1),
+                                        (rig.intrinsic2, rig.distCoeffs2, rig.Rcommon.dot(rig.R.T), rig.K2, rig.mapx2, rig.mapy2)):
+        for (u, v) in ((10, 20), (w // 2, h // 2), (w - 7, h - 3)):
+            ray = np.linalg.inv(Knew.dot(Rr)).dot([u, v, 1.0])
+            x, y = ray[0] / ray[2], ray[1] / ray[2]
+            xd, yd = _rigs._distort(np.array([x]), np.array([y]), _rigs._dist_vector(dist))
+            assert np.isclose(K[0, 0] * xd[0] + K[0, 2], mx[v, u], atol=1e-2)
+            assert np.isclose(K[1, 1] * yd[0] + K[1, 2], my[v, u], atol=1e-2)
+            back = _rigs._undistort_points([[mx[v, u], my[v, u]]], K, dist)
+            assert np.allclose(back[0], [x, y], atol=1e-5)
+
+
+def test_remap_bilinear_on_linear_ramp_and_borders():
+    ys, xs = np.mgrid[0:40, 0:60]
+    img = (2 * xs + 3 * ys).astype(np.float32)
+    mapx = (xs * 0.5 + 3.25).astype(np.float32)
+    mapy = (ys * 0.75 + 1.5).astype(np.float32)
+    out = _rigs._remap(img, mapx, mapy)
+    inside = (mapx < 59) & (mapy < 39)
+    assert np.allclose(out[inside], (2 * mapx + 3 * mapy)[inside], atol=1e-3)      # bilinear is exact on ramps
+    u8 = np.clip(img, 0, 255).astype(np.uint8)
+    far = _rigs._remap(np.dstack([u8] * 3), mapx + 1000, mapy)
+    assert far.shape == (40, 60, 3) and far.dtype == np.uint8 and not far.any()    # constant border
+    assert far.flags["C_CONTIGUOUS"]
+    near = _rigs._remap(u8, np.rint(mapx), np.rint(mapy), interpolation=0)
+    assert near[5, 7] == u8[int(np.rint(mapy[5, 7])), int(np.rint(mapx[5, 7]))]
+
+
+def test_rectify_images_feeds_matcher_shapes():
+    rig = ss.RectifiedStereoRig.fromFile(RIGRECT)
+    rig.computeRectificationMaps(destDims=(160, 90))
+    w, h = rig.res1
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 255, (h, w, 3)).astype(np.uint8)
+    r1, r2 = rig.rectifyImages(a, a[:, ::-1].copy())
+    assert r1.shape == (90, 160, 3) and r2.shape == (90, 160, 3) and r1.dtype == np.uint8
+    assert r1.flags["C_CONTIGUOUS"] and r2.flags["C_CONTIGUOUS"]
+
+
+def test_get3dpoints_matches_q_algebra():
+    rig = ss.RectifiedStereoRig.fromFile(RIGRECT)
+    rig.computeRectificationMaps(destDims=(64, 36))
+    d = np.full((36, 64), 7, np.int16)
+    pts = rig.get3DPoints(d)
+    assert pts.shape == (36, 64, 3) and pts.dtype == np.float32
+    Q = rig.getQ()
+    v = Q.dot([10.0, 20.0, 7.0, 1.0])
+    assert np.allclose(pts[20, 10], v[:3] / v[3], rtol=1e-5)
+    ys, xs = np.mgrid[0:36, 0:64]
+    allp = np.stack([xs, ys, np.full_like(xs, 7), np.ones_like(xs)], -1).astype(np.float64).dot(Q.T)
+    assert np.allclose(pts, (allp[..., :3] / allp[..., 3:]).astype(np.float32), rtol=1e-5)
