@@ -45,7 +45,7 @@ GAMMA_C, GAMMA_P = 5.0, 17.5
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (=157.3 TFLOP/s fp32 FMA)
 ALGO_BYTES_PER_PIXEL = 34        # read 2 x 16 B records, write 2 B
-VALU_OPS_PER_TAP = 4             # cvt_ubyte + mul + fma + add per window tap
+VALU_OPS_PER_TAP = 4             # nominal lane-ops per window tap: mul + 2 fma (N, S') + amortised cvt/sub
 
 
 def count_taps(H, W, win, maxD, minD, row0=0, rows=None):
@@ -209,6 +209,14 @@ def main():
         taps_here = count_taps(H, W, win, maxD, minD, r0, rows_here)
         achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         geom = _native.asw_geometry(W, rows_here, win, maxD, minD)
+        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (tools/prof_bench.sh), if committed
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if world == 1 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = next(v.get("hbm_bytes_per_launch") for k, v in tj.items() if "asw_aggregate_kernel" in k)
+            except Exception:      # noqa: BLE001
+                traffic = None
         line = {
             "metric": "disparity MPixels/s (H*W*nDisp per second)",
             "value": H * W * nD / per_step / 1e6,
@@ -227,7 +235,7 @@ def main():
                        "launch": geom, "checksum": checksum},
             "roofline": {"bound": "hbm", "kernel": "asw_aggregate_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved_gbs / HBM_PEAK_GBS) if achieved_gbs else None,
-                         "traffic": None,
+                         "traffic": traffic,
                          "kernel_ms": k_ms, "launches": launches[_native.K_ASW_AGG],
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "VALU-bound stencil: see 'valu'; HBM figure reported because north_star asks for it"},

@@ -153,8 +153,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
 
     // lanes of a wave run along x (xg fastest): their wL / wR reads are consecutive 16-byte
     // slots (conflict-free ds_read_b128 for any lane grouping)
-    const bool active = tid < g.XG * g.DG;
-    const int xg = tid % g.XG, dg = tid / g.XG;
 
     v2f acc[ASW_RX][ASW_RD];
 #pragma unroll
@@ -178,7 +176,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     }
     // e-build task walk: task t -> (ul = t % nL, dq = t / nL), advanced incrementally
     const int e_q = nthr / nL, e_r = nthr % nL;
-    const int e_ul0 = tid % nL, e_dq0 = tid / nL;
     const int nDq = Dc >> 2;
 
     const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
@@ -202,6 +199,10 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     for (int i = i_lo; i < i_hi; ++i) {
         const int r = y - p + i;
 
+        // per-phase thread indices are re-derived from an opaque copy of the thread id so that
+        // they are not kept live across the aggregation loop (168-VGPR budget, no scratch spills)
+        int tidb = threadIdx.x;
+        asm volatile("" : "+v"(tidb));
         // ---- pixels of image row r were staged into buffer (i & 1) during the previous
         //      iteration's aggregation (prologue for the first row): global latency is hidden
         float4 *const labLc = labL + (i & 1) * nL, *const labRc = labR + (i & 1) * nR;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         {
             const float *const prow = A.prox + i * win;
             const int ncen = Tx + nRc;
-            for (int t = tid; t < ncen * g.wseg; t += nthr) {
+            for (int t = tidb; t < ncen * g.wseg; t += nthr) {
                 const int sgm = t / ncen, c = t - sgm * ncen;
                 const bool isL = c < Tx;
                 const int cc = isL ? c : c - Tx;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|), 4 bytes/task
         //      (_passive.cpp:77-79); pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels
         {
-            int ul = e_ul0, dq = e_dq0;
+            int ul = tidb % nL, dq = tidb / nL;
             while (dq < nDq) {
                 const uint32_t lp = bgrLc[ul];
                 const int rbase = ul + (Dc - 1) - 4 * dq;     // index of R[u-d] for d = dlo+4dq
@@ -259,7 +260,10 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         if (i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
 
         // ---- aggregation over the tap columns j of this window row
-        if (active) {
+        int tidm = threadIdx.x;
+        asm volatile("" : "+v"(tidm));
+        if (tidm < g.XG * g.DG) {
+            const int xg = tidm % g.XG, dg = tidm / g.XG;
             const float *wLp = wL + ASW_RX * xg;
             const float *wRp = wR + (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD);
             const int ul0 = ASW_RX * xg;
@@ -288,7 +292,10 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     }
 
     // ---- weighted average (_passive.cpp:88) and the two WTA reductions
-    if (active) {
+    int tidf = threadIdx.x;
+    asm volatile("" : "+v"(tidf));
+    if (tidf < g.XG * g.DG) {
+        const int xg = tidf % g.XG, dg = tidf / g.XG;
         u64 diag[ASW_RX + ASW_RD - 1];
 #pragma unroll
         for (int k = 0; k < ASW_RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;
