@@ -30,15 +30,17 @@
 
 namespace ssamd {
 
-static constexpr int ASW_RX = 4;      // columns per thread
-static constexpr int ASW_RD = 8;      // disparities per thread
+static constexpr int ASW_RX = 8;      // columns per thread
+static constexpr int ASW_RD = 4;      // disparities per thread (one packed dword of e per row)
+static constexpr int ASW_NWR = (ASW_RX + ASW_RD - 1 + 3) / 4 * 4;   // right weights read per tap column (float4 granules)
 static constexpr int ASW_MAX_THREADS = 768;
+static_assert(ASW_RX == 8 && ASW_RD == 4, "the main loop is unrolled for an 8x4 register tile");
 
 struct AswGeom {
     int Tx, XG, DG, Dc, nchunks, threads;
     int nL, nR, nRc, SR, Se, emask;
     int wseg, wlen;              // weight build: tap columns split in wseg segments of wlen
-    int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen;
+    int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
 };
 
@@ -67,33 +69,36 @@ static constexpr float ASW_TAD_CAP = 40.0f;
 // by 1e-6 and less: occlusions, textureless areas) are both resolved, which a
 // fp32 (sum w*e)/(sum w) cannot do.  The WTA key is built from whichever form is
 // accurate (asw_cost_key).
-__device__ __forceinline__ v2f asw_epair(uint32_t word, int byte)
-{
-    const float e = (float)((word >> (8 * byte)) & 0xffu);   // v_cvt_f32_ubyteN
-    return v2f{e, ASW_TAD_CAP - e};
-}
+struct AswRow {                 // one e row of the register window: e and 40-e for the thread's disparities
+    float e[ASW_RD], c[ASW_RD];
+};
 
-__device__ __forceinline__ void asw_row_pairs(v2f (&row)[ASW_RD], const uint2 packed)
+__device__ __forceinline__ void asw_row_unpack(AswRow &row, const uint32_t packed)
 {
-#pragma unroll
-    for (int di = 0; di < ASW_RD; ++di) row[di] = asw_epair(di < 4 ? packed.x : packed.y, di & 3);
-}
-
-// 32 taps of one tap column for the thread's 4x8 register tile.
-// r0..r3: (e, 40-e) pairs of the e rows of the thread's 4 columns at this tap column.
-__device__ __forceinline__ void asw_taps(v2f (&acc)[ASW_RX][ASW_RD], const float4 wl4, const float4 wa,
-                                         const float4 wb, const float4 wc, const v2f (&r0)[ASW_RD],
-                                         const v2f (&r1)[ASW_RD], const v2f (&r2)[ASW_RD], const v2f (&r3)[ASW_RD])
-{
-    const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
-    const float wr[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
     for (int di = 0; di < ASW_RD; ++di) {
-        const float w0 = wl[0] * wr[7 - di], w1 = wl[1] * wr[8 - di], w2 = wl[2] * wr[9 - di], w3 = wl[3] * wr[10 - di];
-        acc[0][di] = __builtin_elementwise_fma(v2f{w0, w0}, r0[di], acc[0][di]);
-        acc[1][di] = __builtin_elementwise_fma(v2f{w1, w1}, r1[di], acc[1][di]);
-        acc[2][di] = __builtin_elementwise_fma(v2f{w2, w2}, r2[di], acc[2][di]);
-        acc[3][di] = __builtin_elementwise_fma(v2f{w3, w3}, r3[di], acc[3][di]);
+        const float e = (float)((packed >> (8 * di)) & 0xffu);   // v_cvt_f32_ubyteN
+        row.e[di] = e;
+        row.c[di] = ASW_TAD_CAP - e;
+    }
+}
+
+// RX*RD taps of one tap column.  ROT: window slot of the thread's first column (slots rotate
+// by one per tap column; the rotation is resolved at compile time by unrolling RX columns).
+template <int ROT>
+__device__ __forceinline__ void asw_taps(float (&accN)[ASW_RX][ASW_RD], float (&accS)[ASW_RX][ASW_RD],
+                                         const float (&wl)[ASW_RX], const float (&wr)[ASW_NWR],
+                                         const AswRow (&win)[ASW_RX])
+{
+#pragma unroll
+    for (int xi = 0; xi < ASW_RX; ++xi) {
+        const AswRow &row = win[(ROT + xi) % ASW_RX];
+#pragma unroll
+        for (int di = 0; di < ASW_RD; ++di) {
+            const float w = wl[xi] * wr[xi - di + ASW_RD - 1];
+            accN[xi][di] = fmaf(w, row.e[di], accN[xi][di]);
+            accS[xi][di] = fmaf(w, row.c[di], accS[xi][di]);
+        }
     }
 }
 
@@ -101,9 +106,9 @@ __device__ __forceinline__ void asw_taps(v2f (&acc)[ASW_RX][ASW_RD], const float
 // cost itself.  cost <= 20: bits(cost); cost > 20: 0xC0000000 - bits(40 - cost), which
 // is > bits(20.0f) and decreasing in (40 - cost): a monotone map of the cost that keeps
 // the resolution of the accurate operand.
-__device__ __forceinline__ uint32_t asw_cost_key(const v2f acc, float &cost)
+__device__ __forceinline__ uint32_t asw_cost_key(const float n, const float s, float &cost)
 {
-    const float n = acc.x, s = acc.y, t40 = n + s;
+    const float t40 = n + s;
     if (n <= s) {
         cost = ASW_TAD_CAP * n / t40;
         return __float_as_uint(cost);
@@ -113,12 +118,12 @@ __device__ __forceinline__ uint32_t asw_cost_key(const v2f acc, float &cost)
     return 0xC0000000u - __float_as_uint(inv);
 }
 
-// e tile addressing: rows of Se bytes (Se = 8 * power of two >= Dc), the 8-byte slot of
-// disparity group dg in row ul is XOR-swizzled with (ul >> 2) so that the 32 lanes of a
-// ds_read_b64 group (consecutive xg, rows 4 apart) hit 32 distinct bank pairs.
+// e tile addressing: rows of Se bytes (Se = 4 * power of two >= DG), one dword (RD = 4 disparities)
+// per disparity group; the dword slot of group dg in row ul is XOR-swizzled with (ul / RX) so that
+// the lanes of a wave (consecutive xg, rows RX apart) read distinct banks.
 __device__ __forceinline__ int asw_e_offset(int ul, int slot, int Se, int emask)
 {
-    return ul * Se + ((slot ^ ((ul >> 2) & emask)) << 3);
+    return ul * Se + ((slot ^ ((ul / ASW_RX) & emask)) << 2);
 }
 
 template <bool WITH_COSTS>
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     u64 *const bestL = reinterpret_cast<u64 *>(smem + g.off_bestL);
     u64 *const bestR = reinterpret_cast<u64 *>(smem + g.off_bestR);
     float4 *const cenLab = reinterpret_cast<float4 *>(smem + g.off_cen);
+    float *const proxS = reinterpret_cast<float *>(smem + g.off_prox);
 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int W = A.W, win = A.win, p = A.pad;
@@ -154,15 +160,16 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     // lanes of a wave run along x (xg fastest): their wL / wR reads are consecutive 16-byte
     // slots (conflict-free ds_read_b128 for any lane grouping)
 
-    v2f acc[ASW_RX][ASW_RD];
+    float accN[ASW_RX][ASW_RD], accS[ASW_RX][ASW_RD];
 #pragma unroll
     for (int a = 0; a < ASW_RX; ++a)
 #pragma unroll
-        for (int b = 0; b < ASW_RD; ++b) acc[a][b] = v2f{0.f, 0.f};
+        for (int b = 0; b < ASW_RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
 
     for (int k = tid; k < Tx; k += nthr) bestL[k] = KEY_NONE;
     for (int k = tid; k <= nRc; k += nthr) bestR[k] = KEY_NONE;
 
+    for (int k = tid; k < win * win; k += nthr) proxS[k] = A.prox[k];
     // window centres (row y) of the tile: left columns x0.., then right columns xrc_lo..
     for (int c = tid; c < Tx + nRc; c += nthr) {
         const bool isL = c < Tx;
@@ -175,8 +182,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         cenLab[c] = v;
     }
     // e-build task walk: task t -> (ul = t % nL, dq = t / nL), advanced incrementally
-    const int e_q = nthr / nL, e_r = nthr % nL;
-    const int nDq = Dc >> 2;
 
     const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
     // stage the pixels of image row r this tile touches into staging buffer `buf`
@@ -213,9 +218,10 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         // ---- support weights of window row i (_passive.cpp:47-50 and 71-74;
         //      exp(-dist/gammaC) = exp2(dist*kC)).  Task = (window centre c, segment of the
         //      tap columns); consecutive lanes take consecutive centres: conflict-free
-        //      ds_read_b128 of the staged pixels and coalesced LDS writes.
+        //      ds_read_b128 of the staged pixels and coalesced LDS writes.  Branch-free: taps or
+        //      centres outside the image get weight 0 through a bit mask.
         {
-            const float *const prow = A.prox + i * win;
+            const float *const prow = proxS + i * win;          // proximity weights, staged in LDS
             const int ncen = Tx + nRc;
             for (int t = tidb; t < ncen * g.wseg; t += nthr) {
                 const int sgm = t / ncen, c = t - sgm * ncen;
@@ -227,34 +233,34 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                 const int stride = isL ? Tx : SR;
                 const int col0 = (isL ? x0 : xrc_lo) + cc - p;
                 const int j1 = min(win, (sgm + 1) * g.wlen);
+                const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
+#pragma unroll 4
                 for (int j = sgm * g.wlen; j < j1; ++j) {
                     const float4 tp = seg[j];
                     const float dL = tp.x - cen.x, da = tp.y - cen.y, db = tp.z - cen.z;
                     const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
-                    float w = prow[j] * __builtin_amdgcn_exp2f(dist * A.kC);
-                    if (cen.w == 0.f || (unsigned)(col0 + j) >= (unsigned)W) w = 0.f;   // outside the image
-                    wout[j * stride] = w;
+                    const float w = prow[j] * __builtin_amdgcn_exp2f(dist * A.kC);
+                    const uint32_t m = (unsigned)(col0 + j) < (unsigned)W ? cmask : 0u;
+                    wout[j * stride] = __uint_as_float(__float_as_uint(w) & m);
                 }
             }
         }
 
-        // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|), 4 bytes/task
-        //      (_passive.cpp:77-79); pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels
-        {
-            int ul = tidb % nL, dq = tidb / nL;
-            while (dq < nDq) {
-                const uint32_t lp = bgrLc[ul];
-                const int rbase = ul + (Dc - 1) - 4 * dq;     // index of R[u-d] for d = dlo+4dq
-                uint32_t packed = 0;
+        // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|) (_passive.cpp:77-79);
+        //      pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels.  Task = (tap column ul,
+        //      pair of disparity groups = 8 disparities); consecutive lanes = consecutive ul.
+        for (int t = tidb; t < nL * ((g.DG + 1) >> 1); t += nthr) {
+            const int sp = t / nL, ul = t - sp * nL;
+            const uint32_t lp = bgrLc[ul];
+            const uint32_t *const rp = bgrRc + (ul + (Dc - 1) - 8 * sp);   // R[u-d] for d = dlo + 8*sp
+            uint32_t lo = 0, hi = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t s = min(__builtin_amdgcn_sad_u8(lp, bgrRc[rbase - k], 0u), 40u);
-                    packed |= s << (8 * k);
-                }
-                *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, dq >> 1, Se, emask) + 4 * (dq & 1)) = packed;
-                ul += e_r; dq += e_q;
-                if (ul >= nL) { ul -= nL; ++dq; }
+            for (int k = 0; k < 4; ++k) {
+                lo |= min(__builtin_amdgcn_sad_u8(lp, rp[-k], 0u), 40u) << (8 * k);
+                hi |= min(__builtin_amdgcn_sad_u8(lp, rp[-4 - k], 0u), 40u) << (8 * k);
             }
+            *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp, Se, emask)) = lo;
+            if (2 * sp + 1 < g.DG) *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp + 1, Se, emask)) = hi;
         }
         __syncthreads();   // wL, wR, e ready
         if (i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
@@ -264,30 +270,47 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         asm volatile("" : "+v"(tidm));
         if (tidm < g.XG * g.DG) {
             const int xg = tidm % g.XG, dg = tidm / g.XG;
-            const float *wLp = wL + ASW_RX * xg;
-            const float *wRp = wR + (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD);
-            const int ul0 = ASW_RX * xg;
-#define SSAMD_E(n) (*reinterpret_cast<const uint2 *>(eT + asw_e_offset(ul0 + (n), dg, Se, emask)))
-#define SSAMD_W4(ptr, off) (*reinterpret_cast<const float4 *>((ptr) + (off)))
-#define SSAMD_STEP(j, ra, rb, rc, rd)                                                           \
-    if ((j) < win) {                                                                            \
-        asw_row_pairs(rd, SSAMD_E((j) + 3));                                                    \
-        asw_taps(acc, SSAMD_W4(wLp, (j) * Tx), SSAMD_W4(wRp, (j) * SR),                         \
-                 SSAMD_W4(wRp, (j) * SR + 4), SSAMD_W4(wRp, (j) * SR + 8), ra, rb, rc, rd);     \
-    }
-            v2f e0[ASW_RD], e1[ASW_RD], e2[ASW_RD], e3[ASW_RD];
-            asw_row_pairs(e0, SSAMD_E(0));
-            asw_row_pairs(e1, SSAMD_E(1));
-            asw_row_pairs(e2, SSAMD_E(2));
-            for (int j0 = 0; j0 < win; j0 += 4) {
-                SSAMD_STEP(j0, e0, e1, e2, e3)
-                SSAMD_STEP(j0 + 1, e1, e2, e3, e0)
-                SSAMD_STEP(j0 + 2, e2, e3, e0, e1)
-                SSAMD_STEP(j0 + 3, e3, e0, e1, e2)
+            // three running LDS pointers (advanced by one tap column per step) keep the address
+            // arithmetic at ~4 VALU ops per step and nothing step-specific live across the loop
+            const float *wlp = wL + ASW_RX * xg;
+            const float *wrp = wR + (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD);
+            const unsigned char *erow = eT + (ASW_RX * xg) * Se;
+            // swizzled dword slot of this thread's disparity group: depends on row / RX only, i.e. it
+            // changes once per RX tap columns (rows ul0 .. ul0+RX-1 share slot0)
+            int q = xg;
+            int slotA = (dg ^ (q & emask)) << 2;
+            AswRow ew[ASW_RX];
+#pragma unroll
+            for (int n = 0; n < ASW_RX - 1; ++n) {
+                asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow + slotA));
+                erow += Se;
             }
+            for (int j0 = 0; j0 < win; j0 += ASW_RX) {
+                const int slotB = (dg ^ ((q + 1) & emask)) << 2;
+#define SSAMD_STEP(JJ, SLOT)                                                                        \
+    if (j0 + (JJ) < win) {                                                                          \
+        asw_row_unpack(ew[((JJ) + ASW_RX - 1) % ASW_RX], *reinterpret_cast<const uint32_t *>(erow + (SLOT))); \
+        erow += Se;                                                                                 \
+        float wl[ASW_RX], wr[ASW_NWR];                                                              \
+        _Pragma("unroll") for (int qq = 0; qq < ASW_RX / 4; ++qq) {                                 \
+            const float4 v = *reinterpret_cast<const float4 *>(wlp + 4 * qq);                      \
+            wl[4 * qq] = v.x; wl[4 * qq + 1] = v.y; wl[4 * qq + 2] = v.z; wl[4 * qq + 3] = v.w;     \
+        }                                                                                           \
+        _Pragma("unroll") for (int qq = 0; qq < ASW_NWR / 4; ++qq) {                                \
+            const float4 v = *reinterpret_cast<const float4 *>(wrp + 4 * qq);                      \
+            wr[4 * qq] = v.x; wr[4 * qq + 1] = v.y; wr[4 * qq + 2] = v.z; wr[4 * qq + 3] = v.w;     \
+        }                                                                                           \
+        wlp += Tx; wrp += SR;                                                                       \
+        asw_taps<(JJ)>(accN, accS, wl, wr, ew);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+                // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards
+                SSAMD_STEP(0, slotA) SSAMD_STEP(1, slotB) SSAMD_STEP(2, slotB) SSAMD_STEP(3, slotB)
+                SSAMD_STEP(4, slotB) SSAMD_STEP(5, slotB) SSAMD_STEP(6, slotB) SSAMD_STEP(7, slotB)
 #undef SSAMD_STEP
-#undef SSAMD_W4
-#undef SSAMD_E
+                slotA = slotB;
+                ++q;
+            }
         }
     }
 
@@ -309,9 +332,9 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
                 if (valid) {
                     float c;
-                    const u64 hi = (u64)asw_cost_key(acc[xi][di], c) << 32;
+                    const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
                     bl = min(bl, hi | (u64)(uint32_t)d);
-                    diag[xi - di + 7] = min(diag[xi - di + 7], hi | (u64)(uint32_t)x);
+                    diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
                         A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
                 }

@@ -169,10 +169,11 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     g.nL = g.Tx + 2 * p;
     g.nRc = g.Tx + g.Dc - 1;
     g.nR = g.nRc + 2 * p;
-    g.SR = round_up(g.nRc + 1, 4);
-    int P = 8;                                  // 8-byte slots per e row: power of two >= DG
-    while (P < DG) P <<= 1;
-    g.Se = 8 * P;
+    g.SR = round_up(g.nRc + 4, 4);
+    int P = 8;                                  // dword slots per e row: closed under XOR with emask
+    while (P < DG && P < 32) P <<= 1;           //   power of two up to 32, then multiples of 32
+    if (P < DG) P = round_up(DG, 32);
+    g.Se = 4 * P;
     g.emask = std::min(P, 32) - 1;
     // weight build balance: (centres x segments) tasks over the workgroup's threads
     {
@@ -196,6 +197,7 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     g.off_bestL = take((size_t)g.Tx * 8);
     g.off_bestR = take((size_t)(g.nRc + 1) * 8);
     g.off_cen = take((size_t)(g.Tx + g.nRc) * 16);
+    g.off_prox = take((size_t)win * win * 4);
     g.lds_bytes = (int)off;
     return off <= limit;
 }
@@ -227,7 +229,7 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
     for (int nch = 1; nch <= nD; ++nch) {
         const int per = (nD + nch - 1) / nch;
         const int DG = round_up(per, ASW_RD) / ASW_RD;
-        if (DG > 64) continue;
+        if (DG > 128) continue;
         if ((nD + DG * ASW_RD - 1) / (DG * ASW_RD) != nch) continue;
         const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + ASW_RX - 1) / ASW_RX);
         for (int XG = xg_cap; XG >= 1; --XG) {
