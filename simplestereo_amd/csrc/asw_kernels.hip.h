@@ -302,7 +302,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         }                                                                                           \
         wlp += Tx; wrp += SR;                                                                       \
         asw_taps<(JJ)>(accN, accS, wl, wr, ew);                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
     }
                 // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards
                 SSAMD_STEP(0, slotA) SSAMD_STEP(1, slotB) SSAMD_STEP(2, slotB) SSAMD_STEP(3, slotB)
