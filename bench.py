@@ -153,8 +153,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SSAMD_BENCH_FORCE_DIST") == "1"   # FORCE: exercise the RCCL path at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import simplestereo_amd as ss
@@ -172,13 +174,13 @@ def main():
                                    consistent=args.consistent)
 
     def step():
-        if world == 1:
+        if not use_dist:
             return matcher.compute(ownL, ownR)
         return strips.match_strip(matcher, ownL, ownR, H, rank, world, gather=True)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -195,7 +197,7 @@ def main():
     dt = time.perf_counter() - t0
     ms, launches = _native.profile_read()
     lib.ssamd_profile_enable(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -249,10 +251,15 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.cpu_budget)
             if line["cpu_baseline"]["value"]:
                 line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        result = json.dumps(line)
+    else:
+        result = None
+    if use_dist:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # RCCL may print banner lines on teardown: keep the JSON line last
+    sys.stdout.flush()
+    if result is not None:
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

@@ -101,7 +101,7 @@ def gather_strips(strip_disparity, height, rank, world_size, group=None):
     """All-gather the per-rank disparity strips into the full [height, W] map (on every rank)."""
     import torch
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not dist.is_initialized():
         return strip_disparity
     W = strip_disparity.shape[1]
     rows_max = -(-int(height) // world_size)
