@@ -249,18 +249,23 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|) (_passive.cpp:77-79);
         //      pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels.  Task = (tap column ul,
         //      pair of disparity groups = 8 disparities); consecutive lanes = consecutive ul.
-        for (int t = tidb; t < nL * ((g.DG + 1) >> 1); t += nthr) {
-            const int sp = t / nL, ul = t - sp * nL;
-            const uint32_t lp = bgrLc[ul];
-            const uint32_t *const rp = bgrRc + (ul + (Dc - 1) - 8 * sp);   // R[u-d] for d = dlo + 8*sp
-            uint32_t lo = 0, hi = 0;
+        {
+            const int nsp = (g.DG + 1) >> 1, e_q = nthr / nL, e_r = nthr - e_q * nL;
+            int sp = tidb / nL, ul = tidb - sp * nL;
+            while (sp < nsp) {
+                const uint32_t lp = bgrLc[ul];
+                const uint32_t *const rp = bgrRc + (ul + (Dc - 1) - 8 * sp);   // R[u-d] for d = dlo + 8*sp
+                uint32_t lo = 0, hi = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lo |= min(__builtin_amdgcn_sad_u8(lp, rp[-k], 0u), 40u) << (8 * k);
-                hi |= min(__builtin_amdgcn_sad_u8(lp, rp[-4 - k], 0u), 40u) << (8 * k);
+                for (int k = 0; k < 4; ++k) {
+                    lo |= min(__builtin_amdgcn_sad_u8(lp, rp[-k], 0u), 40u) << (8 * k);
+                    hi |= min(__builtin_amdgcn_sad_u8(lp, rp[-4 - k], 0u), 40u) << (8 * k);
+                }
+                *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp, Se, emask)) = lo;
+                if (2 * sp + 1 < g.DG) *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp + 1, Se, emask)) = hi;
+                ul += e_r; sp += e_q;
+                if (ul >= nL) { ul -= nL; ++sp; }
             }
-            *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp, Se, emask)) = lo;
-            if (2 * sp + 1 < g.DG) *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp + 1, Se, emask)) = hi;
         }
         __syncthreads();   // wL, wR, e ready
         if (i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
@@ -268,8 +273,14 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         // ---- aggregation over the tap columns j of this window row
         int tidm = threadIdx.x;
         asm volatile("" : "+v"(tidm));
-        if (tidm < g.XG * g.DG) {
-            const int xg = tidm % g.XG, dg = tidm / g.XG;
+        // a register tile contributes only if some (x,d) of it is a candidate the reference evaluates
+        // (x - d >= 0, d <= maxDisparity, x < W); waves whose lanes are all outside (left image border,
+        // padded disparities) skip the aggregation -- wave-uniform, decided once per window row
+        const int xg_m = tidm % g.XG, dg_m = tidm / g.XG;
+        const bool tile_live = tidm < g.XG * g.DG && x0 + ASW_RX * xg_m < W && dlo + ASW_RD * dg_m <= A.maxD &&
+                               x0 + ASW_RX * xg_m + ASW_RX - 1 - (dlo + ASW_RD * dg_m) >= 0;
+        if (__builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG) {
+            const int xg = xg_m, dg = dg_m;
             // three running LDS pointers (advanced by one tap column per step) keep the address
             // arithmetic at ~4 VALU ops per step and nothing step-specific live across the loop
             const float *wlp = wL + ASW_RX * xg;
