@@ -34,11 +34,12 @@ static constexpr int ASW_RX = 8;      // columns per thread
 static constexpr int ASW_RD = 4;      // disparities per thread (one packed dword of e per row)
 static constexpr int ASW_NWR = (ASW_RX + ASW_RD - 1 + 3) / 4 * 4;   // right weights read per tap column (float4 granules)
 static constexpr int ASW_MAX_THREADS = 768;
-static_assert(ASW_RX == 8 && ASW_RD == 4, "the main loop is unrolled for an 8x4 register tile");
+static_assert(ASW_RX == 8 && ASW_RD == 4 && ASW_NWR == 12, "the main loop is unrolled for an 8x4 register tile");
 
 struct AswGeom {
     int Tx, XG, DG, Dc, nchunks, threads;
     int nL, nR, nRc, SR, Se, emask;
+    int SL, hL, hR;              // wL row stride and the half offsets of the parity-split wL / wR rows
     int wseg, wlen;              // weight build: tap columns split in wseg segments of wlen
     int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
@@ -116,6 +117,15 @@ __device__ __forceinline__ uint32_t asw_cost_key(const float n, const float s, f
     const float inv = ASW_TAD_CAP * s / t40;
     cost = ASW_TAD_CAP - inv;
     return 0xC0000000u - __float_as_uint(inv);
+}
+
+// wL / wR rows are stored with their even and odd 16-byte blocks in two halves ("parity split"):
+// element c lives at  ((c >> 2) & 1) * half + ((c >> 3) << 2) + (c & 3).  A thread reads RX = 8
+// consecutive columns = one even + one odd block, so for each ds_read_b128 the lanes of a wave
+// (consecutive column groups) are 16 bytes apart instead of 32: no 2-way bank conflicts.
+__device__ __forceinline__ int asw_split_pos(int c, int half)
+{
+    return ((c >> 2) & 1) * half + ((c >> 3) << 2) + (c & 3);
 }
 
 // e tile addressing: rows of Se bytes (Se = 4 * power of two >= DG), one dword (RD = 4 disparities)
@@ -229,8 +239,8 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                 const int cc = isL ? c : c - Tx;
                 const float4 cen = cenLab[c];                      // centre pixel (row y); .w = inside image
                 const float4 *const seg = (isL ? labLc : labRc) + cc;
-                float *const wout = (isL ? wL : wR) + cc;
-                const int stride = isL ? Tx : SR;
+                float *const wout = (isL ? wL : wR) + asw_split_pos(cc, isL ? g.hL : g.hR);
+                const int stride = isL ? g.SL : SR;
                 const int col0 = (isL ? x0 : xrc_lo) + cc - p;
                 const int j1 = min(win, (sgm + 1) * g.wlen);
                 const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
@@ -283,8 +293,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
             const int xg = xg_m, dg = dg_m;
             // three running LDS pointers (advanced by one tap column per step) keep the address
             // arithmetic at ~4 VALU ops per step and nothing step-specific live across the loop
-            const float *wlp = wL + ASW_RX * xg;
-            const float *wrp = wR + (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD);
+            const float *wlp = wL + ASW_RX / 2 * xg;                  // even block of the thread's columns; odd block at + hL
+            // right weights: ASW_NWR/4 consecutive 4-float blocks starting at block b0 (parity-split rows)
+            const int b0 = (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD) >> 2;
+            const float *wrp0 = wR + (b0 & 1) * g.hR + ((b0 >> 1) << 2);
+            const float *wrp1 = wR + ((b0 + 1) & 1) * g.hR + (((b0 + 1) >> 1) << 2);
+            const float *wrp2 = wR + (b0 & 1) * g.hR + (((b0 + 2) >> 1) << 2);
             const unsigned char *erow = eT + (ASW_RX * xg) * Se;
             // swizzled dword slot of this thread's disparity group: depends on row / RX only, i.e. it
             // changes once per RX tap columns (rows ul0 .. ul0+RX-1 share slot0)
@@ -303,15 +317,19 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         asw_row_unpack(ew[((JJ) + ASW_RX - 1) % ASW_RX], *reinterpret_cast<const uint32_t *>(erow + (SLOT))); \
         erow += Se;                                                                                 \
         float wl[ASW_RX], wr[ASW_NWR];                                                              \
-        _Pragma("unroll") for (int qq = 0; qq < ASW_RX / 4; ++qq) {                                 \
-            const float4 v = *reinterpret_cast<const float4 *>(wlp + 4 * qq);                      \
-            wl[4 * qq] = v.x; wl[4 * qq + 1] = v.y; wl[4 * qq + 2] = v.z; wl[4 * qq + 3] = v.w;     \
+        {                                                                                           \
+            const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                              \
+            const float4 v1 = *reinterpret_cast<const float4 *>(wlp + g.hL);                       \
+            wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                                 \
+            wl[4] = v1.x; wl[5] = v1.y; wl[6] = v1.z; wl[7] = v1.w;                                 \
+            const float4 r0 = *reinterpret_cast<const float4 *>(wrp0);                             \
+            const float4 r1 = *reinterpret_cast<const float4 *>(wrp1);                             \
+            const float4 r2 = *reinterpret_cast<const float4 *>(wrp2);                             \
+            wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                                 \
+            wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                                 \
+            wr[8] = r2.x; wr[9] = r2.y; wr[10] = r2.z; wr[11] = r2.w;                               \
         }                                                                                           \
-        _Pragma("unroll") for (int qq = 0; qq < ASW_NWR / 4; ++qq) {                                \
-            const float4 v = *reinterpret_cast<const float4 *>(wrp + 4 * qq);                      \
-            wr[4 * qq] = v.x; wr[4 * qq + 1] = v.y; wr[4 * qq + 2] = v.z; wr[4 * qq + 3] = v.w;     \
-        }                                                                                           \
-        wlp += Tx; wrp += SR;                                                                       \
+        wlp += g.SL; wrp0 += SR; wrp1 += SR; wrp2 += SR;                                            \
         asw_taps<(JJ)>(accN, accS, wl, wr, ew);                                                     \
     }
                 // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards

@@ -169,7 +169,12 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     g.nL = g.Tx + 2 * p;
     g.nRc = g.Tx + g.Dc - 1;
     g.nR = g.nRc + 2 * p;
-    g.SR = round_up(g.nRc + 4, 4);
+    // parity-split rows (asw_split_pos): two halves of ceil(n/8)*4 floats; +1 block so that the halves
+    // start on different banks phases and reads one block past the end stay inside the row
+    g.hL = (g.Tx / 8) * 4 + 4;
+    g.SL = 2 * g.hL;
+    g.hR = ((g.nRc + 4 + 7) / 8) * 4 + 4;
+    g.SR = 2 * g.hR;
     int P = 8;                                  // dword slots per e row: closed under XOR with emask
     while (P < DG && P < 32) P <<= 1;           //   power of two up to 32, then multiples of 32
     if (P < DG) P = round_up(DG, 32);
@@ -187,7 +192,7 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    g.off_wL = take((size_t)win * g.Tx * 4);
+    g.off_wL = take((size_t)win * g.SL * 4);
     g.off_wR = take((size_t)win * g.SR * 4);
     g.off_e = take((size_t)g.nL * g.Se);
     g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
