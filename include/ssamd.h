@@ -86,6 +86,20 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream);
 
+/* ---- the steps either side of the matchers, on device --------- */
+
+/* RectifiedStereoRig.rectifyImages (reference _rigs.py:543-567 = cv2.remap with constant
+ * border): d_dst[y][x] = bilinear(d_src, d_mapx[y][x], d_mapy[y][x]).  d_src is uint8
+ * [src_h][src_w][3]; maps are float32 [dst_h][dst_w] (cv2.initUndistortRectifyMap layout,
+ * built once per rig on the host); interpolation 0 = nearest, 1 = linear. */
+int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
+                           int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream);
+
+/* RectifiedStereoRig.get3DPoints (reference _rigs.py:569-628 = cv2.reprojectImageTo3D):
+ * d_points float32 [h][w][3] from int16 disparities and the 4x4 matrix Q (16 doubles, row
+ * major, HOST memory). */
+int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const double *Q, float *d_points, void *stream);
+
 /* ---- verification / measurement helpers ------------------------------------ */
 
 /* Raw left-referenced aggregated ASW costs, float32 [height][width][nD] with
@@ -108,7 +122,9 @@ int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int dev
 #define SSAMD_K_ASW_FIN 2    /* ASW key decode / LR check / occlusion fill       */
 #define SSAMD_K_GSW_AGG 3    /* GSW weights + cost aggregation + WTA keys        */
 #define SSAMD_K_GSW_FIN 4    /* GSW LR check / occlusion fill                    */
-#define SSAMD_K_COUNT 5
+#define SSAMD_K_REMAP 5      /* rectification remap (bilinear)                    */
+#define SSAMD_K_REPROJECT 6  /* disparity -> 3-D points                           */
+#define SSAMD_K_COUNT 7
 int ssamd_profile_enable(int on);
 int ssamd_profile_reset(void);
 int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);

@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_COUNT = 0, 1, 2, 3, 4, 5
+K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
 
 _lib = None
 _u8p = ctypes.c_void_p
@@ -52,6 +52,10 @@ def lib():
     L.ssamd_asw_costs.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
     L.ssamd_bgr2lab.restype = I
     L.ssamd_bgr2lab.argtypes = [P, I, I, P, I]
+    L.ssamd_remap_bgr_device.restype = I
+    L.ssamd_remap_bgr_device.argtypes = [P, I, I, P, P, I, I, I, P, P]
+    L.ssamd_reproject_device.restype = I
+    L.ssamd_reproject_device.argtypes = [P, I, I, ctypes.POINTER(D), P, P]
     L.ssamd_profile_enable.restype = I
     L.ssamd_profile_enable.argtypes = [I]
     L.ssamd_profile_reset.restype = I

@@ -187,6 +187,10 @@ def _fitting_matrix(K1, K2, H1, H2, dims1, dims2, dist1=None, dist2=None, destDi
     return Kz.dot(Fit)
 
 
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
 class StereoRig:
     """
     Keep together and manage all parameters of a calibrated stereo rig
@@ -377,9 +381,41 @@ class RectifiedStereoRig(StereoRig):
         """
         Undistort, rectify and fit a couple of images coming from the stereo rig.  Returns two
         C-contiguous arrays of the destination resolution, ready for ``StereoASW.compute``.
+
+        Extension: two CUDA/HIP ``torch.uint8 [H,W,3]`` tensors are remapped on the GPU
+        (``remap_bgr_kernel``; the maps are uploaded once per rig and device) and returned as
+        device tensors, so the rectified pair can go straight into ``compute`` without a host
+        round trip.
         """
+        if _is_device_tensor(img1) and _is_device_tensor(img2):
+            return (self._remap_device(img1, 1, interpolation), self._remap_device(img2, 2, interpolation))
         return (_remap(img1, self.mapx1, self.mapy1, interpolation),
                 _remap(img2, self.mapx2, self.mapy2, interpolation))
+
+    def _remap_device(self, img, which, interpolation):
+        import ctypes
+        import torch
+        from . import _native
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("device rectification expects uint8 [H,W,3] tensors")
+        if interpolation not in (INTER_NEAREST, INTER_LINEAR):
+            raise NotImplementedError("only INTER_NEAREST (0) and INTER_LINEAR (1) are available")
+        mx, my = (self.mapx1, self.mapy1) if which == 1 else (self.mapx2, self.mapy2)
+        key = (which, str(img.device), mx.ctypes.data, mx.shape)
+        cache = self.__dict__.setdefault("_dev_maps", {})
+        if key not in cache:                      # maps change only through computeRectificationMaps
+            cache[key] = (torch.from_numpy(np.ascontiguousarray(mx)).to(img.device),
+                          torch.from_numpy(np.ascontiguousarray(my)).to(img.device))
+        dmx, dmy = cache[key]
+        src = img.contiguous()
+        h, w = mx.shape
+        out = torch.empty((h, w, 3), dtype=torch.uint8, device=img.device)
+        with torch.cuda.device(img.device):
+            stream = torch.cuda.current_stream(img.device).cuda_stream
+            _native.check(_native.lib().ssamd_remap_bgr_device(src.data_ptr(), int(src.shape[0]), int(src.shape[1]),
+                                                               dmx.data_ptr(), dmy.data_ptr(), h, w, int(interpolation),
+                                                               out.data_ptr(), ctypes.c_void_p(stream)))
+        return out
 
     def getQ(self):
         """The 4x4 disparity-to-depth matrix built by the reference in get3DPoints (_rigs.py:604-625)."""
@@ -405,6 +441,8 @@ class RectifiedStereoRig(StereoRig):
         3D points (height, width, 3) float32 from a disparity map, world origin in the left camera:
         [X Y Z W]^T = Q [x y d 1]^T, point = (X/W, Y/W, Z/W)  (cv2.reprojectImageTo3D semantics).
         """
+        if _is_device_tensor(disparityMap):
+            return self._get3DPoints_device(disparityMap)
         d = np.asarray(disparityMap)
         h, w = d.shape[:2]
         Q = self.getQ()
@@ -414,3 +452,21 @@ class RectifiedStereoRig(StereoRig):
         with np.errstate(divide="ignore", invalid="ignore"):
             out = p[..., :3] / p[..., 3:4]
         return out.astype(np.float32)
+
+    def _get3DPoints_device(self, disp):
+        """int16 disparity tensor on the GPU -> float32 [H,W,3] point tensor on the GPU (reproject_kernel)."""
+        import ctypes
+        import torch
+        from . import _native
+        if disp.dtype != torch.int16 or disp.dim() != 2:
+            raise ValueError("device reprojection expects an int16 [H,W] tensor")
+        d = disp.contiguous()
+        h, w = int(d.shape[0]), int(d.shape[1])
+        Q = np.ascontiguousarray(self.getQ(), dtype=np.float64)
+        out = torch.empty((h, w, 3), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            stream = torch.cuda.current_stream(d.device).cuda_stream
+            _native.check(_native.lib().ssamd_reproject_device(d.data_ptr(), h, w,
+                                                               Q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                               out.data_ptr(), ctypes.c_void_p(stream)))
+        return out

@@ -179,7 +179,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     for (int k = tid; k < Tx; k += nthr) bestL[k] = KEY_NONE;
     for (int k = tid; k <= nRc; k += nthr) bestR[k] = KEY_NONE;
 
-    for (int k = tid; k < win * win; k += nthr) proxS[k] = A.prox[k];
     // window centres (row y) of the tile: left columns x0.., then right columns xrc_lo..
     for (int c = tid; c < Tx + nRc; c += nthr) {
         const bool isL = c < Tx;
@@ -197,6 +196,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     // stage the pixels of image row r this tile touches into staging buffer `buf`
     // (coalesced 16 B loads; columns outside the image become zero records)
     auto stage_row = [&](int r, int buf) {
+        for (int k = tid; k < win; k += nthr) proxS[buf * win + k] = A.prox[(r - (y - p)) * win + k];
         const PixRec *const rowL = A.recL + (size_t)r * W;
         const PixRec *const rowR = A.recR + (size_t)r * W;
         for (int k = tid; k < nL + nR; k += nthr) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         //      ds_read_b128 of the staged pixels and coalesced LDS writes.  Branch-free: taps or
         //      centres outside the image get weight 0 through a bit mask.
         {
-            const float *const prow = proxS + i * win;          // proximity weights, staged in LDS
+            const float *const prow = proxS + (i & 1) * win;    // proximity weights of window row i, staged in LDS
             const int ncen = Tx + nRc;
             for (int t = tidb; t < ncen * g.wseg; t += nthr) {
                 const int sgm = t / ncen, c = t - sgm * ncen;

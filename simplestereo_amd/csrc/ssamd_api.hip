@@ -17,6 +17,7 @@
 #include "asw_kernels.hip.h"
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
+#include "rig_kernels.hip.h"
 
 using namespace ssamd;
 
@@ -202,7 +203,7 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     g.off_bestL = take((size_t)g.Tx * 8);
     g.off_bestR = take((size_t)(g.nRc + 1) * 8);
     g.off_cen = take((size_t)(g.Tx + g.nRc) * 16);
-    g.off_prox = take((size_t)win * win * 4);
+    g.off_prox = take((size_t)win * 4 * 2);      // one window row of proximity weights, double-buffered
     g.lds_bytes = (int)off;
     return off <= limit;
 }
@@ -497,7 +498,7 @@ int ssamd_device_count(void)
 const char *ssamd_kernel_name(int slot)
 {
     static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel", "asw_aggregate_kernel", "asw finalize (wta_decode / lr_check_fill)",
-                                               "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)"};
+                                               "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
 }
 
@@ -627,6 +628,45 @@ int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width, i
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(disparity, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
+                           int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!d_src || !d_mapx || !d_mapy || !d_dst) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (interpolation != 0 && interpolation != 1) return fail(SSAMD_EINVAL, "only INTER_NEAREST (0) and INTER_LINEAR (1) are supported");
+    Ctx *c;
+    int rc = get_ctx(-1, &c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long long npix = (long long)dst_h * dst_w;
+    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 16);
+    Timed t(*c, s, SSAMD_K_REMAP);
+    hipLaunchKernelGGL(remap_bgr_kernel, dim3(blocks), dim3(256), 0, s, d_src, src_h, src_w, d_mapx, d_mapy, d_dst, npix,
+                       interpolation == 0 ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const double *Q, float *d_points, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!d_disparity || !Q || !d_points) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (h <= 0 || w <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    Ctx *c;
+    int rc = get_ctx(-1, &c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Mat4 q;
+    for (int k = 0; k < 16; ++k) q.m[k] = Q[k];
+    const long long npix = (long long)h * w;
+    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 16);
+    Timed t(*c, s, SSAMD_K_REPROJECT);
+    hipLaunchKernelGGL(reproject_kernel, dim3(blocks), dim3(256), 0, s, d_disparity, d_points, h, w, q);
+    HIP_TRY(hipGetLastError());
     return SSAMD_OK;
 }
 
