@@ -9,10 +9,11 @@
 //
 // Work decomposition
 //   workgroup  = (image row y, tile of Tx left columns, chunk of Dc disparities)
-//   thread     = register tile of RX=4 columns x RD=8 disparities, 2 fp32
-//                accumulators (cost, weight sum) per (x,d) pair
+//   thread     = register tile of RX=8 columns x RD=4 disparities, 2 fp32 accumulators
+//                (N, S' -- see below) per (x,d) pair
 //   outer loop = the window rows i (tap row r = y - pad + i).  Per window row the
-//                workgroup stages the pixels it needs in LDS and builds, in LDS,
+//                workgroup stages the pixels it needs in LDS (prefetched one row ahead) and
+//                builds, in LDS,
 //                  wL[j][x]   left support weights  (x in tile, tap column j)
 //                  wR[j][xr]  right support weights (xr = x - d over the tile: they
 //                             do not depend on x, the reference re-evaluates them
@@ -20,11 +21,14 @@
 //                  e[u][d]    truncated absolute difference of L[r][u], R[r][u-d]
 //                             as bytes: it depends on the tap column u = x+j-pad
 //                             only, so each value serves up to `win` taps
-//   inner loop = tap columns j; per step a thread reads 4 wL, 12 wR (b128 reads)
-//                and ONE new 8-byte row of e (the other three slide in registers),
-//                then does 32 taps x {cvt_ubyte, mul, fma, add}.
+//   inner loop = tap columns j; per step a thread reads 8 wL + 12 wR values (five
+//                ds_read_b128, 16-byte lane stride thanks to the parity-split rows) and
+//                ONE new dword of e (the other seven rows of its window slide in
+//                registers), then does 32 taps x {v_mul, 2 v_fma} + 4 x {cvt_ubyte, sub}.
 // HBM traffic is the pixel records only (16 B/pixel/image, re-read from L2 by
 // neighbouring tiles) plus 8-byte WTA keys; everything else lives in LDS/VGPRs.
+// Measured (1080p, D 0..192, win 35): 48.9 ms, 3.6e10 VALU wave-instructions at ~83 % of the
+// plain fp32 issue rate, no scratch, LDS ~50 % busy (profiles/).
 #pragma once
 #include "common.hip.h"
 
