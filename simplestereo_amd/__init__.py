@@ -14,6 +14,7 @@ The matchers run as hand-written HIP kernels (gfx950) behind the C ABI of
 from . import passive
 from ._rigs import StereoRig, RectifiedStereoRig
 from . import strips
+from . import points
 
 __version__ = "0.1.0"
-__all__ = ["passive", "StereoRig", "RectifiedStereoRig", "strips"]
+__all__ = ["passive", "StereoRig", "RectifiedStereoRig", "strips", "points"]

@@ -116,3 +116,37 @@ def test_get3dpoints_matches_q_algebra():
     ys, xs = np.mgrid[0:36, 0:64]
     allp = np.stack([xs, ys, np.full_like(xs, 7), np.ones_like(xs)], -1).astype(np.float64).dot(Q.T)
     assert np.allclose(pts, (allp[..., :3] / allp[..., 3:]).astype(np.float32), rtol=1e-5)
+
+
+def test_ply_round_trip_and_reference_header(tmp_path):
+    """points.exportPLY / importPLY (reference points.py:10-121): header lines and column order"""
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(4, 5, 3))
+    img = rng.integers(0, 255, (4, 5, 3)).astype(np.uint8)
+    f = tmp_path / "c.ply"
+    ss.points.exportPLY(pts, str(f), img, precision=4)
+    lines = open(f).read().splitlines()
+    assert lines[:3] == ["ply", "format ascii 1.0", "comment SimpleStereo point cloud export"]
+    assert lines[3] == "comment Original array shape 4x5x3" and lines[4] == "element vertex 20"
+    assert lines[5:11] == ["property double x", "property double y", "property double z",
+                           "property uchar red", "property uchar green", "property uchar blue"]
+    assert lines[11] == "end_header" and len(lines) == 12 + 20
+    back = ss.points.importPLY(str(f))
+    assert back.shape == (20, 3) and np.allclose(back, pts.reshape(-1, 3), atol=1e-4)
+    rgb = ss.points.importPLY(str(f), 3, 4, 5)
+    assert np.array_equal(rgb.astype(np.uint8), img.reshape(-1, 3)[:, ::-1])          # BGR stored as RGB
+    g = tmp_path / "g.ply"
+    ss.points.exportPLY(pts, str(g), img[..., 0].astype(np.int64))
+    assert "property int intensity" in open(g).read()
+    h = tmp_path / "h.ply"
+    ss.points.exportPLY(pts, str(h))
+    assert ss.points.importPLY(str(h)).shape == (20, 3)
+
+
+def test_adimensional_points_geometry():
+    d = np.full((6, 8), 2, np.int16)
+    p = ss.points.getAdimensional3DPoints(d)
+    assert p.shape == (6, 8, 3) and p.dtype == np.float32
+    # centre pixel maps to x = y = 0; depth = -f*b/d with f = width, b = 1
+    assert np.allclose(p[3, 4], [0.0, 0.0, -8 / 2.0])
+    assert np.allclose(p[..., 2], -4.0)
