@@ -99,23 +99,23 @@ class StereoASW():
     Adaptive Support-Weight stereo matching (K. Yoon, I. Kweon, 2006) -- drop-in for
     ``simplestereo.passive.StereoASW`` (reference ``passive.py:16-92``).
 
-    Parameters
+    Parameters (same names, order and defaults as the reference constructor)
     ----------
     winSize : int
-        Side of the square window. Must be an odd positive number. Default is 35.
-    maxDisparity: int
-        Maximum accepted disparity. Default is 16.
-    minDisparity: int
-        Minimum valid disparity, usually set to zero. Default is 0.
+        Edge length of the square support window in pixels; odd and positive (default 35).
+    maxDisparity : int
+        Largest disparity that is tried, inclusive (default 16).
+    minDisparity : int
+        Smallest disparity that is tried, inclusive (default 0; negative values are refused).
     gammaC : float
-        Color parameter. If increased, it increases the color influence. Default is 5.
+        Scale of the colour term exp(-dLab / gammaC) of the support weights (default 5).
     gammaP : float
-        Proximity parameter. If increased, it increases the proximity influence. Default is 17.5.
+        Scale of the spatial term exp(-dist / gammaP) of the support weights (default 17.5).
     consistent : bool
-        If True the disparity is also computed with the right image as reference; any
-        non-corresponding value is invalidated (occluded) and filled with the nearest
-        minimum left-right non-occluded disparity.  On the GPU this costs one extra
-        reduction, not a second aggregation (the aggregated cost is symmetric).
+        Also match with the right image as reference, invalidate left pixels whose match does
+        not agree, and fill each invalid run with the smaller of its two valid neighbours
+        (default False).  On the GPU this costs one extra reduction, not a second aggregation,
+        because the aggregated cost is symmetric in the (left pixel, right pixel) pair.
     """
 
     def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False):
@@ -135,17 +135,11 @@ class StereoASW():
 
     def compute(self, img1, img2):
         """
-        Compute disparity map for BGR images.
+        Disparity map of a rectified BGR pair.
 
-        Parameters
-        ----------
-        img1, img2 : numpy.ndarray (uint8, [H,W,3], BGR as returned by cv2.imread)
-            Left and right rectified images of the same shape.
-
-        Returns
-        -------
-        numpy.ndarray (np.int16)
-            A disparity map of the same width and height of the images.
+        img1, img2: left and right image, ``numpy.uint8`` arrays ``[H, W, 3]`` in OpenCV channel
+        order (or two device tensors, see the module docstring).  Returns a new ``numpy.int16``
+        array ``[H, W]`` of left-referenced disparities.
         """
         if _is_device_tensor(img1) and _is_device_tensor(img2):
             return self._compute_device(img1, img2)
@@ -195,22 +189,22 @@ class StereoGSW():
     right-referenced winner-take-all on geodesically weighted, truncated colour
     distances, left-right check and occlusion filling (always on).
 
-    Parameters
+    Parameters (same names, order and defaults as the reference constructor)
     ----------
-    winSize : int, optional
-        Side of the square window. Must be an odd positive number. Default is 11.
-    maxDisparity: int, optional
-        Maximum accepted disparity. Default is 16.
-    minDisparity: int, optional
-        Minimum valid disparity, usually set to zero. Default is 0.
-    gamma : int, optional
-        Gamma parameter (must be an int, like the reference's "i" format). Default is 10.
-    fMax : int or float, optional
-        Color difference is capped to this value. Default is 120.
-    iterations : int, optional
-        Number of iteration for geodesic distances estimation. Default is 3.
-    bins : int, optional
-        Accepted and unused (the reference never reads it). Default is 20.
+    winSize : int
+        Edge length of the square support window; odd and positive (default 11).
+    maxDisparity, minDisparity : int
+        Inclusive disparity search range (defaults 16 and 0).
+    gamma : int
+        Scale of exp(-geodesic distance / gamma); must be an ``int`` because the reference parses
+        it with the "i" format (default 10).
+    fMax : int or float
+        Cap of the per-pixel colour distance (default 120).
+    iterations : int
+        Relaxation sweeps of the reference's distance transform; any value >= 1 gives the same
+        weights, 0 keeps only the window centre (default 3).
+    bins : int
+        Accepted for signature compatibility; the reference never reads it (default 20).
     """
 
     def __init__(self, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20):
@@ -229,9 +223,7 @@ class StereoGSW():
                 _c_double(self.fMax), _c_int(self.iterations), _c_int(self.bins))
 
     def compute(self, img1, img2):
-        """
-        Compute disparity map for 3-color channel images.
-        """
+        """Disparity map of a rectified 3-channel pair (uint8 [H,W,3]); returns int16 [H,W]."""
         if _is_device_tensor(img1) and _is_device_tensor(img2):
             return self._compute_device(img1, img2)
         lib = _native.lib()
