@@ -173,10 +173,12 @@ def main():
     matcher = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
                                    consistent=args.consistent)
 
+    strip_ctx = strips.StripContext(matcher, H, W, rank, world, dev) if use_dist else None
+
     def step():
         if not use_dist:
             return matcher.compute(ownL, ownR)
-        return strips.match_strip(matcher, ownL, ownR, H, rank, world, gather=True)
+        return strip_ctx.step(ownL, ownR, gather=True)
 
     def fence():
         torch.cuda.synchronize()

@@ -22,7 +22,8 @@ strips of the result are collected with one all_gather on equal-padded strips.
 """
 import numpy as np
 
-__all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip"]
+__all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip",
+           "StripContext"]
 
 
 def strip_bounds(height, world_size, rank):
@@ -128,6 +129,72 @@ def match_strip(matcher, own_left, own_right, height, rank, world_size, group=No
     subL, subR, out_row0, out_rows = exchange_halos(own_left, own_right, height, pad, rank, world_size, group)
     strip = matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows)
     return gather_strips(strip, height, rank, world_size, group) if gather else strip
+
+
+class StripContext:
+    """Reusable state of one rank for repeated frames of the same geometry: the transfer plan,
+    the sub-image buffers (strip + halos) and the gather buffers are built once, so that a step is
+    two device copies, one batched isend/irecv group, the kernels and one all_gather_into_tensor.
+
+        ctx = StripContext(matcher, height, width, rank, world_size, device)
+        full = ctx.step(own_left, own_right)        # full [height, width] int16 map on every rank
+    """
+
+    def __init__(self, matcher, height, width, rank, world_size, device, group=None):
+        import torch
+        self.matcher, self.H, self.W = matcher, int(height), int(width)
+        self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.pad = int(matcher.winSize) // 2
+        self.r0, self.r1 = strip_bounds(self.H, self.world, self.rank)
+        self.h0, self.h1 = halo_bounds(self.H, self.r0, self.r1, self.pad)
+        self.subL = torch.zeros((self.h1 - self.h0, self.W, 3), dtype=torch.uint8, device=device)
+        self.subR = torch.zeros_like(self.subL)
+        mine = [t for t in transfer_plan(self.H, self.world, self.pad) if self.rank in (t[0], t[1])]
+        self.sends = [(dst, lo - self.r0, hi - self.r0) for src, dst, lo, hi in mine if src == self.rank]
+        self.recvs = [(src, lo - self.h0, hi - self.h0) for src, dst, lo, hi in mine if dst == self.rank]
+        self.send_bufs = [(torch.empty((hi - lo, self.W, 3), dtype=torch.uint8, device=device),
+                           torch.empty((hi - lo, self.W, 3), dtype=torch.uint8, device=device)) for _, lo, hi in self.sends]
+        self.rows_max = -(-self.H // self.world)
+        self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=device)
+        self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=device)
+        self.full = torch.empty((self.H, self.W), dtype=torch.int16, device=device)
+
+    def step(self, own_left, own_right, gather=True):
+        import torch
+        import torch.distributed as dist
+        o0, o1 = self.r0 - self.h0, self.r1 - self.h0
+        self.subL[o0:o1].copy_(own_left)
+        self.subR[o0:o1].copy_(own_right)
+        if self.world > 1 and (self.sends or self.recvs):
+            ops = []
+            for (dst, lo, hi), (bl, br) in zip(self.sends, self.send_bufs):
+                bl.copy_(own_left[lo:hi])
+                br.copy_(own_right[lo:hi])
+                ops.append(dist.P2POp(dist.isend, bl, dst, group=self.group))
+                ops.append(dist.P2POp(dist.isend, br, dst, group=self.group))
+            for src, lo, hi in self.recvs:
+                ops.append(dist.P2POp(dist.irecv, self.subL[lo:hi], src, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, self.subR[lo:hi], src, group=self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        strip = self.matcher._compute_device(self.subL, self.subR, out_row0=o0, out_rows=self.r1 - self.r0)
+        if not gather:
+            return strip
+        if self.world == 1 and not dist.is_initialized():
+            return strip
+        self.padded[:strip.shape[0]].copy_(strip)
+        # int16 is not an RCCL collective dtype: gather the strips as bytes
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.gathered.view(torch.uint8), self.padded.view(torch.uint8), group=self.group)
+        else:                                    # gloo (CPU tests) has no flat all-gather
+            parts = list(self.gathered.view(torch.uint8).unbind(0))
+            dist.all_gather(parts, self.padded.view(torch.uint8), group=self.group)
+        if self.H == self.rows_max * self.world:
+            return self.gathered.view(self.H, self.W)
+        for r in range(self.world):
+            a, b = strip_bounds(self.H, self.world, r)
+            self.full[a:b].copy_(self.gathered[r, :b - a])
+        return self.full
 
 
 def split_rows(image, world_size):

@@ -59,6 +59,10 @@ def _worker(rank, world, port, H, W, pad, seed, q):
         m = _FakeMatcher(2 * pad + 1)
         full = strips.match_strip(m, L[r0:r1].contiguous(), R[r0:r1].contiguous(), H, rank, world, gather=True)
         ok = ok and torch.equal(full, _FakeMatcher.whole(L, R, pad))
+        ctx = strips.StripContext(m, H, W, rank, world, torch.device("cpu"))
+        for _ in range(2):                                   # reusable across frames
+            again = ctx.step(L[r0:r1].contiguous(), R[r0:r1].contiguous())
+            ok = ok and torch.equal(again, _FakeMatcher.whole(L, R, pad))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
