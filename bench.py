@@ -157,6 +157,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # NCCL_DEBUG=VERSION (set on the GPU boxes) makes RCCL print a banner on C stdout, which is
+        # flushed at exit, i.e. AFTER the JSON line: keep stdout to the one JSON line the contract asks for
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import simplestereo_amd as ss
