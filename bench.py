@@ -138,6 +138,13 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line.  RCCL (NCCL_DEBUG=VERSION on the GPU boxes) and other
+    # native libraries write banners / warnings to C stdout, flushed at exit: keep the real stdout in a
+    # private descriptor and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -157,10 +164,6 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # NCCL_DEBUG=VERSION (set on the GPU boxes) makes RCCL print a banner on C stdout, which is
-        # flushed at exit, i.e. AFTER the JSON line: keep stdout to the one JSON line the contract asks for
-        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import simplestereo_amd as ss
@@ -265,7 +268,7 @@ def main():
         dist.destroy_process_group()      # RCCL may print banner lines on teardown: keep the JSON line last
     sys.stdout.flush()
     if result is not None:
-        print(result, flush=True)
+        os.write(real_stdout, (result + "\n").encode())
 
 
 if __name__ == "__main__":
