@@ -26,7 +26,10 @@ def _cases(n, seed):
         maxD = int(minD + rng.integers(0, 70))
         out.append((H, W, win, minD, maxD, bool(rng.integers(0, 2)), 100 + k))
     out += [(1, 1, 1, 0, 0, True, 7), (1, 50, 9, 0, 20, True, 8), (30, 1, 9, 0, 5, True, 9), (2, 9, 35, 1, 40, False, 10),
-            (17, 130, 5, 0, 129, True, 11), (8, 300, 3, 2, 290, True, 12)]
+            (17, 130, 5, 0, 129, True, 11), (8, 300, 3, 2, 290, True, 12),
+            # disparity range split over several chunks (nD > 512), very large windows
+            (6, 760, 5, 0, 700, True, 13), (5, 1200, 3, 10, 1100, False, 14), (40, 150, 101, 0, 30, True, 15),
+            (70, 90, 69, 3, 40, False, 16)]
     return out
 
 
