@@ -98,6 +98,7 @@ struct Ctx {
     // cached small tables
     int prox_win = -1; double prox_gammaP = -1;
     int gsw_gamma = -1; float gsw_fmax = -1.f;
+    hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
     Profile prof;
 };
 
@@ -129,6 +130,7 @@ int get_ctx(int device, Ctx **out)
     if (c.dev < 0) {
         c.dev = device;
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c.scratch_free, hipEventDisableTiming));
     }
     if (!c.lut_ready) {
         // sRGB byte -> linear*100 in the reference's float arithmetic (colorconversion.hpp:19-37)
@@ -146,6 +148,15 @@ int get_ctx(int device, Ctx **out)
     *out = &c;
     return SSAMD_OK;
 }
+
+// The scratch buffers (pixel records, WTA keys, tables) are shared by every call on a device.  Calls are
+// serialised on the host by g_mutex; across streams the next call's stream waits for the previous call's
+// last kernel, so callers may use any stream without synchronising between operators.
+struct ScratchOrder {
+    Ctx &c; hipStream_t s;
+    ScratchOrder(Ctx &c_, hipStream_t s_) : c(c_), s(s_) { (void)hipStreamWaitEvent(s, c.scratch_free, 0); }
+    ~ScratchOrder() { (void)hipEventRecord(c.scratch_free, s); }
+};
 
 int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
 {
@@ -319,6 +330,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     if (rc) return rc;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
     if (rows == 0) return SSAMD_OK;
+    ScratchOrder order(c, s);
     const int p = win / 2, nD = maxD - minD + 1;
     const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
 
@@ -439,6 +451,7 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     if (rc) return rc;
     if (gamma == 0) return fail(SSAMD_EINVAL, "gamma must be non-zero");
     if (rows == 0) return SSAMD_OK;
+    ScratchOrder order(c, s);
     const int p = win / 2, nD = maxD - minD + 1;
     const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
     if ((rc = c.keyL.reserve(nout * 8)) || (rc = c.keyR.reserve(nout * 8))) return rc;

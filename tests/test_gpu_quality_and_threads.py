@@ -81,3 +81,26 @@ def test_host_and_device_entry_points_agree_1080p(ss):
     t_dev = time.perf_counter() - t
     print("1080p/193/35: host buffers (PCIe inclusive) %.2f ms, resident %.2f ms" % (t_host * 1e3, t_dev * 1e3))
     assert np.array_equal(dev.cpu().numpy(), host)
+
+
+def test_calls_on_different_streams_do_not_race_on_scratch(ss, golden_inputs):
+    """device entry points are asynchronous; the library orders its shared scratch across streams"""
+    import torch
+    a, b = golden_inputs("synth_96x128")
+    c, d = golden_inputs("synth_64x96")
+    m1 = ss.passive.StereoASW(winSize=21, maxDisparity=32, consistent=True)
+    m2 = ss.passive.StereoASW(winSize=9, maxDisparity=24)
+    want1, want2 = m1.compute(a, b), m2.compute(c, d)
+    ta, tb, tc, td = (torch.from_numpy(x).cuda() for x in (a, b, c, d))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            o1 = m1.compute(ta, tb)
+        with torch.cuda.stream(s2):
+            o2 = m2.compute(tc, td)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert np.array_equal(o1.cpu().numpy(), want1) and np.array_equal(o2.cpu().numpy(), want2)
