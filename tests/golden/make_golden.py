@@ -101,6 +101,8 @@ def main():
         "G6d": ("synth_64x96", G(winSize=11, maxDisparity=24, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
         "G6e": ("synth_64x96", G(winSize=7, maxDisparity=20, minDisparity=3, gamma=25, fMax=80.5, iterations=2, bins=20)),
         "G6f": ("synth_480x640", A(winSize=35, maxDisparity=64, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False)),
+        "G6g": ("synth_480x640", A(winSize=35, maxDisparity=64, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True)),
+        "G6h": ("synth_480x640", G(winSize=11, maxDisparity=64, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
         "G8a": ("tsukuba_top", G(winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
         "G8b": ("tsukuba_top", A(winSize=21, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True)),
     }

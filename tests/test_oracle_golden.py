@@ -13,7 +13,7 @@ from oracle import oracle
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 with open(os.path.join(GOLDEN, "cases.json")) as _f:
     _META = json.load(_f)
-_SLOW_LITERAL = {"G6f", "G3", "G4"}        # literal mode too slow for the CPU suite budget
+_SLOW_LITERAL = {"G6f", "G6g", "G6h", "G3", "G4"}        # literal mode too slow for the CPU suite budget
 
 
 def _run(cid, meta, inputs, fast):
