@@ -37,6 +37,7 @@ namespace ssamd {
 static constexpr int ASW_RX = 8;      // columns per thread
 static constexpr int ASW_RD = 4;      // disparities per thread (one packed dword of e per row)
 static constexpr int ASW_NWR = (ASW_RX + ASW_RD - 1 + 3) / 4 * 4;   // right weights read per tap column (float4 granules)
+static constexpr int ASW_WB = 4;       // support weights evaluated side by side in the build phase
 static constexpr int ASW_MAX_THREADS = 768;
 static_assert(ASW_RX == 8 && ASW_RD == 4 && ASW_NWR == 12, "the main loop is unrolled for an 8x4 register tile");
 
@@ -248,14 +249,33 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                 const int col0 = (isL ? x0 : xrc_lo) + cc - p;
                 const int j1 = min(win, (sgm + 1) * g.wlen);
                 const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
-#pragma unroll 4
-                for (int j = sgm * g.wlen; j < j1; ++j) {
-                    const float4 tp = seg[j];
-                    const float dL = tp.x - cen.x, da = tp.y - cen.y, db = tp.z - cen.z;
-                    const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
-                    const float w = prow[j] * __builtin_amdgcn_exp2f(dist * A.kC);
-                    const uint32_t m = (unsigned)(col0 + j) < (unsigned)W ? cmask : 0u;
-                    wout[j * stride] = __uint_as_float(__float_as_uint(w) & m);
+                // batches of ASW_WB independent evaluations: all LDS reads first, then the dependent
+                // chains (sub, fma, v_sqrt, v_exp, mul) side by side -- a single chain is ~150 cycles of
+                // latency, and during this phase every wave of the group is in the same loop
+                for (int j = sgm * g.wlen; j < j1; j += ASW_WB) {
+                    float4 tp[ASW_WB];
+                    float pr[ASW_WB], wv[ASW_WB];
+#pragma unroll
+                    for (int u = 0; u < ASW_WB; ++u) {
+                        const int jj = min(j + u, j1 - 1);
+                        tp[u] = seg[jj];
+                        pr[u] = prow[jj];
+                    }
+#pragma unroll
+                    for (int u = 0; u < ASW_WB; ++u) {
+                        const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                        wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                    }
+#pragma unroll
+                    for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                    for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                    for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
+                        const int jj = min(j + u, j1 - 1);
+                        const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
+                        wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                    }
                 }
             }
         }

@@ -198,7 +198,7 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
         int best_cost = 1 << 30;
         for (int ns = 1; ns <= win && ns <= 8; ++ns) {
             const int len = (win + ns - 1) / ns, rounds = (ncen * ns + g.threads - 1) / g.threads;
-            const int cost = rounds * (len + 2);
+            const int cost = rounds * (round_up(len, ASW_WB) + 2);       // evaluated in batches of ASW_WB
             if (cost < best_cost) { best_cost = cost; g.wseg = ns; g.wlen = len; }
         }
     }
