@@ -113,6 +113,10 @@ int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int wi
  * headers/colorconversion.hpp:81-86); float32 [height][width][3]. Host buffers. */
 int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device);
 
+/* The GSW kernels' exact integer square root, evaluated on the device for s = 0 .. n-1 (n <= 195076)
+ * into a HOST buffer: lets a test prove it equals (float)sqrt((double)s) over the whole domain. */
+int ssamd_debug_gsw_sqrt(int n, float *out);
+
 /* Kernel timing with HIP events recorded on the launch stream.  After
  * ssamd_profile_enable(1) every operator call brackets its kernels with events;
  * ssamd_profile_read() synchronises and returns accumulated milliseconds and

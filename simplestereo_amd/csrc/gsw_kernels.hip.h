@@ -49,6 +49,30 @@ struct GswArgs {
     GswGeom g;
 };
 
+// fl32(sqrt(s)) for an INTEGER-valued s in [0, 3*255^2]: v_sqrt_f32 (1 ulp) followed by one
+// Newton step on the exact fma residual.  Equal to the reference's (float)sqrt((double)s) for every
+// such s -- checked exhaustively on the device by tests/test_gpu_gsw.py through ssamd_debug_gsw_sqrt --
+// at a third of the instructions of the general correctly-rounded sqrtf expansion.
+__device__ __forceinline__ float gsw_sqrt_int(float s)
+{
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float h = 0.5f * __builtin_amdgcn_rcpf(r);
+    const float e = fmaf(-r, r, s);
+    const float r1 = fmaf(e, h, r);
+    return s > 0.f ? r1 : 0.f;
+}
+
+__device__ __forceinline__ float4 bgr_unpack(uint32_t v, float valid)
+{
+    return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), valid);
+}
+
+__device__ __forceinline__ float bgr_dist2f(const float4 a, const float4 b)
+{
+    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z;
+    return d0 * d0 + d1 * d1 + d2 * d2;       // integers < 2^24: exact in fp32 whatever the contraction
+}
+
 // |a-b|^2 over the three colour bytes, exact in fp32
 __device__ __forceinline__ float bgr_dist2(uint32_t a, uint32_t b)
 {
@@ -91,8 +115,8 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
     const GswGeom &g = A.g;
     float *const wS = reinterpret_cast<float *>(smem + g.off_w);          // [win][Tx]
     float *const eT = reinterpret_cast<float *>(smem + g.off_e);          // [nL][Se]
-    uint32_t *const refS = reinterpret_cast<uint32_t *>(smem + g.off_ref);   // [nL]
-    uint32_t *const tgtS = reinterpret_cast<uint32_t *>(smem + g.off_tgt);   // [nT]
+    float4 *const refS = reinterpret_cast<float4 *>(smem + g.off_ref);    // [nL] {b, g, r, inside image}
+    float4 *const tgtS = reinterpret_cast<float4 *>(smem + g.off_tgt);    // [nT]
     u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [Tx]
 
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -124,12 +148,12 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
     for (int i = i_lo; i < i_hi; ++i) {
         const int r = y - p + i;
         __syncthreads();                    // previous window row fully consumed
-        for (int k = tid; k < nL + nT; k += nthr) {
-            const bool isRef = k < nL;
+        for (int k = tid; k < nL + nT; k += nthr) {     // staged pixels as floats: converted once per pixel,
+            const bool isRef = k < nL;                   // not once per (pixel, disparity) element
             const int idx = isRef ? k : k - nL;
             const int col = (isRef ? seg_lo : tgt_lo) + idx;
-            uint32_t v = 0u;
-            if ((unsigned)col < (unsigned)W) v = (isRef ? A.ref : A.tgt)[(size_t)r * W + col];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)col < (unsigned)W) v = bgr_unpack((isRef ? A.ref : A.tgt)[(size_t)r * W + col], 1.f);
             (isRef ? refS : tgtS)[idx] = v;
         }
         __syncthreads();
@@ -145,20 +169,45 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
                 if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
                 if (centre) w = 1.0f;                                                   // exp(-0/gamma)
                 else if (reached) {
-                    const uint32_t cpx = A.ref[(size_t)y * W + x];
-                    w = A.tab[(int)bgr_dist2(refS[c + j], cpx)];
+                    const float4 cpx = bgr_unpack(A.ref[(size_t)y * W + x], 1.f);
+                    w = A.tab[(int)bgr_dist2f(refS[c + j], cpx)];
                 }
             }
             wS[j * Tx + c] = w;
         }
-        // ---- e[ul][d] = min(fMax, ||ref(r,u) - tgt(r,u -/+ d)||), 0 when the target column is outside
-        for (int t = tid; t < nL * Dc; t += nthr) {
-            const int dd = t / nL, ul = t - dd * nL;              // consecutive lanes: consecutive columns
-            const int tix = right ? ul + dd : ul + (Dc - 1) - dd;
-            const int tcol = tgt_lo + tix;
-            float e = 0.f;
-            if ((unsigned)tcol < (unsigned)W) e = fminf(A.fMax, __fsqrt_rn(bgr_dist2(refS[ul], tgtS[tix])));
-            eT[gsw_e_offset(ul, dd >> 3, Se, emask) + (dd & 7)] = e;
+        // ---- e[ul][d] = min(fMax, ||ref(r,u) - tgt(r,u -/+ d)||), 0 when the target column is outside.
+        //      Task index (column ul fastest, then disparity) advanced without divisions.
+        //      Task = (column ul, disparity dd) with dd fastest across the lanes of a wave: the e writes of
+        //      a wave then fall into consecutive floats (the column-fastest order put 64 lanes on 4 banks),
+        //      the reference pixel is a broadcast read and the target pixels are consecutive 16-byte reads.
+        //      Four independent elements per iteration (LDS reads first, then the sub/fma/sqrt chains).
+        {
+            const int e_q = nthr / Dc, e_r = nthr - e_q * Dc;
+            int ul = tid / Dc, dd = tid - ul * Dc;
+            while (ul < nL) {
+                int uls[4], dds[4];
+                float4 rp[4], tp[4];
+                float ev[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uls[u] = min(ul, nL - 1); dds[u] = dd;      // tasks past the end repeat the last column
+                    dd += e_r; ul += e_q;
+                    if (dd >= Dc) { dd -= Dc; ++ul; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tix = right ? uls[u] + dds[u] : uls[u] + (Dc - 1) - dds[u];
+                    rp[u] = refS[uls[u]];
+                    tp[u] = tgtS[tix];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ev[u] = bgr_dist2f(rp[u], tp[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ev[u] = fminf(A.fMax, gsw_sqrt_int(ev[u]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    eT[gsw_e_offset(uls[u], dds[u] >> 3, Se, emask) + (dds[u] & 7)] = tp[u].w == 0.f ? 0.f : ev[u];
+            }
         }
         __syncthreads();
 
@@ -208,6 +257,13 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
         const int x = x0 + k;
         if (x < W && best[k] != KEY_NONE) atomicMin(&A.key[orow + x], best[k]);
     }
+}
+
+// verification helper: gsw_sqrt_int over s = 0 .. n-1
+__global__ __launch_bounds__(256) void gsw_sqrt_probe_kernel(float *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gsw_sqrt_int((float)i);
 }
 
 // BGR u8 -> packed dword per pixel (GSW works on raw BGR, _passive.cpp:740-741)

@@ -385,8 +385,8 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, size_t limit)
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
     g.off_w = take((size_t)win * g.Tx * 4);
     g.off_e = take((size_t)g.nL * g.Se * 4);
-    g.off_ref = take((size_t)g.nL * 4);
-    g.off_tgt = take((size_t)g.nT * 4);
+    g.off_ref = take((size_t)g.nL * 16);
+    g.off_tgt = take((size_t)g.nT * 16);
     g.off_best = take((size_t)g.Tx * 8);
     g.lds_bytes = (int)off;
     return off <= limit;
@@ -680,6 +680,22 @@ int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const doubl
     Timed t(*c, s, SSAMD_K_REPROJECT);
     hipLaunchKernelGGL(reproject_kernel, dim3(blocks), dim3(256), 0, s, d_disparity, d_points, h, w, q);
     HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int ssamd_debug_gsw_sqrt(int n, float *out)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!out || n <= 0 || n > GSW_TAB_SIZE) return fail(SSAMD_EINVAL, "bad argument");
+    Ctx *c;
+    int rc = get_ctx(-1, &c);
+    if (rc) return rc;
+    if ((rc = c->lab.reserve((size_t)n * 4))) return rc;
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(gsw_sqrt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (float *)c->lab.ptr, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->lab.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SSAMD_OK;
 }
 

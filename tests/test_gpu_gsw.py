@@ -99,3 +99,13 @@ def test_gsw_1080p_config4_properties(ss):
     good = np.abs(d1.astype(np.int32) - gt)[:, 192:] <= 1
     print("config4 quality vs synthetic GT: %.4f" % good.mean())
     assert good.mean() > 0.6
+
+
+def test_gsw_integer_sqrt_is_exact_over_whole_domain(ss):
+    """the kernels' short sqrt sequence == the reference's (float)sqrt((double)s) for EVERY s it can see"""
+    from simplestereo_amd import _native
+    n = 3 * 255 * 255 + 1
+    out = np.empty(n, np.float32)
+    _native.check(_native.lib().ssamd_debug_gsw_sqrt(n, out.ctypes.data))
+    want = np.sqrt(np.arange(n, dtype=np.float64)).astype(np.float32)
+    assert np.array_equal(out, want)
