@@ -23,6 +23,8 @@ Rank 0 prints ONE JSON line.  metric = disparity MPixels/s = H*W*nD / t / 1e6
   cpu_baseline  the reference's own C++ extension (oracle/_ref, kind "reference") or
                 the plain-C port (oracle/, kind "port", literal mode) timed on this
                 box's host cores on a bounded strip of the same frame.
+  bad1_vs_cpu_ref  the second half of BASELINE's metric: % of pixels of that strip whose GPU
+                disparity differs from the CPU reference's by more than 1 level.
 """
 import argparse
 import json
@@ -80,15 +82,22 @@ a, b = np.ascontiguousarray(L[r0:r0 + rows]), np.ascontiguousarray(R[r0:r0 + row
 ref = oracle.ref_module()
 t = time.time()
 if ref is not None:
-    ref.computeASW(a, b, win, maxD, minD, %r, %r, False); kind = "reference"
+    d = ref.computeASW(a, b, win, maxD, minD, %r, %r, False); kind = "reference"
 else:
-    oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=False); kind = "port"
-print(json.dumps({"t": time.time() - t, "kind": kind, "cores": os.cpu_count()}))
+    d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=False); kind = "port"
+if len(sys.argv) > 2:
+    np.save(sys.argv[2], d)
+print(json.dumps({"t": time.time() - t, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}))
 """ % (ROOT, H, W, maxD, minD, win, seed, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P)
 
+    import tempfile
+    dump = os.path.join(tempfile.gettempdir(), "ssamd_cpu_ref_%d.npy" % os.getpid())
+
     def run(rows, timeout):
-        out = subprocess.run([sys.executable, "-c", code, str(rows)], capture_output=True, text=True, timeout=timeout)
-        return json.loads(out.stdout.strip().splitlines()[-1])
+        out = subprocess.run([sys.executable, "-c", code, str(rows), dump], capture_output=True, text=True, timeout=timeout)
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        res["rows"] = rows
+        return res
 
     cores = os.cpu_count() or 1
     try:
@@ -118,7 +127,7 @@ print(json.dumps({"t": time.time() - t, "kind": kind, "cores": os.cpu_count()}))
         full = count_taps(H, W, win, maxD, minD)
         t_full = res["t"] * full / taps                   # per-tap cost is uniform
         return {"value": H * W * (maxD - minD + 1) / t_full / 1e6, "unit": "MPixels*disp/s", "cores": res["cores"],
-                "kind": res["kind"],
+                "kind": res["kind"], "strip_row0": res["r0"], "strip_rows": rows, "map_file": dump,
                 "sample": "%dx%d centre strip (%d rows) of the same frame, %.3g of the frame's %.4g window taps, "
                           "%.1f s wall on %d host threads; scaled to the full frame by tap count" %
                           (W, rows, rows, taps / full, float(full), res["t"], res["cores"])}
@@ -257,9 +266,22 @@ def main():
             "kernels_ms_per_step": {_native.lib().ssamd_kernel_name(i).decode(): ms[i] / args.steps for i in range(_native.K_COUNT) if launches[i]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.cpu_budget)
-            if line["cpu_baseline"]["value"]:
-                line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            cb = cpu_baseline(cfg, args.seed, args.cpu_budget)
+            # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
+            # the CPU baseline computed (matched as a stand-alone sub-image by both)
+            try:
+                ref_map = np.load(cb.pop("map_file"))
+                r0s, rws = cb["strip_row0"], cb["strip_rows"]
+                gpu_map = matcher.compute(np.ascontiguousarray(L[r0s:r0s + rws]), np.ascontiguousarray(R[r0s:r0s + rws]))
+                diff = np.abs(gpu_map.astype(np.int32) - ref_map.astype(np.int32))
+                line["bad1_vs_cpu_ref"] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
+                                           "pixels": int(diff.size), "what": "GPU vs CPU %s map of the cpu_baseline strip" % cb["kind"]}
+            except Exception as e:      # noqa: BLE001
+                line["bad1_vs_cpu_ref"] = {"percent": None, "what": repr(e)[:160]}
+            cb.pop("map_file", None)
+            line["cpu_baseline"] = cb
+            if cb["value"]:
+                line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
         result = json.dumps(line)
     else:
         result = None
