@@ -267,7 +267,11 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
             const double nwg = (double)xt * std::max(rows, 1) * nch, slots = 256.0 * k;
             const double tail = nwg / (std::ceil(nwg / slots) * slots);
             const double overlap = k > 1 ? 1.05 : 1.0;             // independent groups hide each other's build phase
-            const double score = (double)k * XG * DG * (M / (M + B)) * d_util * x_util * tail * overlap;
+            // the busiest SIMD carries k*per_simd waves: a group's time scales with per_simd, and fewer
+            // resident waves hide less latency (measured: 2 waves/SIMD ~0.85x, 1 wave/SIMD ~0.6x of 3)
+            const int wps = k * per_simd;
+            const double occ = wps >= 3 ? 1.0 : (wps == 2 ? 0.85 : 0.6);
+            const double score = (double)XG * DG / per_simd * occ * (M / (M + B)) * d_util * x_util * tail * overlap;
             if (score > best_score) { best_score = score; best = g; found = true; }
         }
         if (DG <= 2) break;
