@@ -161,7 +161,13 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int W = A.W, win = A.win, p = A.pad;
     const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nR = g.nR, nRc = g.nRc, SR = g.SR, Se = g.Se, emask = g.emask;
-    const int x0 = blockIdx.x * Tx;
+    // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a
+    // speed assumption only).  When the row has a multiple of 8 x tiles, tile slot b of every row lands on
+    // XCD b % 8; give each XCD a run of ADJACENT tiles (slots b, b+8, ... -> tiles m*(b%8) + b/8, m = tiles/8)
+    // so that the halo columns neighbouring tiles share are served by one L2 instead of two.
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int x0 = bx * Tx;
     const int y = A.row0 + blockIdx.y;
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
