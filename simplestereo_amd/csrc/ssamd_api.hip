@@ -166,6 +166,7 @@ int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
     if (W > 32767 || maxD > 32767) return fail(SSAMD_ELIMIT, "width / maxDisparity exceed the int16 disparity range");
     if (row0 < 0 || rows < 0 || row0 + rows > H) return fail(SSAMD_EINVAL, "output row range [%d,%d) outside the image (height %d)", row0, row0 + rows, H);
     if (win > 255) return fail(SSAMD_ELIMIT, "winSize %d > 255 not supported", win);
+    if (rows > 65535) return fail(SSAMD_ELIMIT, "more than 65535 output rows per call: split the image into row strips");
     return SSAMD_OK;
 }
 
