@@ -45,7 +45,8 @@ struct AswGeom {
     int Tx, XG, DG, Dc, nchunks, threads;
     int nL, nR, nRc, SR, Se, emask;
     int SL, hL, hR;              // wL row stride and the half offsets of the parity-split wL / wR rows
-    int wseg, wlen;              // weight build: tap columns split in wseg segments of wlen
+    int wseg, wlen;              // weight build: tap columns (of a chunk) split in wseg segments of wlen
+    int JC;                      // tap columns staged per chunk (multiple of ASW_RX); >= win: one chunk
     int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
 };
@@ -141,7 +142,8 @@ __device__ __forceinline__ int asw_e_offset(int ul, int slot, int Se, int emask)
     return ul * Se + ((slot ^ ((ul / ASW_RX) & emask)) << 2);
 }
 
-template <bool WITH_COSTS>
+// CHUNKED: the tap columns of a window row are staged g.JC at a time (see the loop over jc below).
+template <bool WITH_COSTS, bool CHUNKED>
 __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const AswArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -222,6 +224,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
             (isL ? bgrL + buf * nL : bgrR + buf * nR)[idx] = v.bgrx;
         }
     };
+    // Tap columns are staged JC at a time when the whole window row of weights does not leave room for
+    // enough resident waves (small disparity ranges: few threads share a weight row); chunk buffers
+    // alternate so that one barrier per chunk suffices.  JC == win: a single chunk, rows used in place.
+    const int JC = CHUNKED ? g.JC : win;
+    int cb = 0;
     for (int i = i_lo; i < i_hi; ++i) {
         const int r = y - p + i;
 
@@ -235,56 +242,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         uint32_t *const bgrLc = bgrL + (i & 1) * nL, *const bgrRc = bgrR + (i & 1) * nR;
         if (i == i_lo) stage_row(r, i & 1);
         __syncthreads();   // staged pixels visible; every thread is done with main(i-1)
-
-        // ---- support weights of window row i (_passive.cpp:47-50 and 71-74;
-        //      exp(-dist/gammaC) = exp2(dist*kC)).  Task = (window centre c, segment of the
-        //      tap columns); consecutive lanes take consecutive centres: conflict-free
-        //      ds_read_b128 of the staged pixels and coalesced LDS writes.  Branch-free: taps or
-        //      centres outside the image get weight 0 through a bit mask.
-        {
-            const float *const prow = proxS + (i & 1) * win;    // proximity weights of window row i, staged in LDS
-            const int ncen = Tx + nRc;
-            for (int t = tidb; t < ncen * g.wseg; t += nthr) {
-                const int sgm = t / ncen, c = t - sgm * ncen;
-                const bool isL = c < Tx;
-                const int cc = isL ? c : c - Tx;
-                const float4 cen = cenLab[c];                      // centre pixel (row y); .w = inside image
-                const float4 *const seg = (isL ? labLc : labRc) + cc;
-                float *const wout = (isL ? wL : wR) + asw_split_pos(cc, isL ? g.hL : g.hR);
-                const int stride = isL ? g.SL : SR;
-                const int col0 = (isL ? x0 : xrc_lo) + cc - p;
-                const int j1 = min(win, (sgm + 1) * g.wlen);
-                const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
-                // batches of ASW_WB independent evaluations: all LDS reads first, then the dependent
-                // chains (sub, fma, v_sqrt, v_exp, mul) side by side -- a single chain is ~150 cycles of
-                // latency, and during this phase every wave of the group is in the same loop
-                for (int j = sgm * g.wlen; j < j1; j += ASW_WB) {
-                    float4 tp[ASW_WB];
-                    float pr[ASW_WB], wv[ASW_WB];
-#pragma unroll
-                    for (int u = 0; u < ASW_WB; ++u) {
-                        const int jj = min(j + u, j1 - 1);
-                        tp[u] = seg[jj];
-                        pr[u] = prow[jj];
-                    }
-#pragma unroll
-                    for (int u = 0; u < ASW_WB; ++u) {
-                        const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
-                        wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
-                    }
-#pragma unroll
-                    for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
-#pragma unroll
-                    for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
-#pragma unroll
-                    for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
-                        const int jj = min(j + u, j1 - 1);
-                        const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
-                        wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
-                    }
-                }
-            }
-        }
 
         // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|) (_passive.cpp:77-79);
         //      pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels.  Task = (tap column ul,
@@ -307,43 +264,102 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                 if (ul >= nL) { ul -= nL; ++sp; }
             }
         }
-        __syncthreads();   // wL, wR, e ready
-        if (i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
 
-        // ---- aggregation over the tap columns j of this window row
+        // ---- per-row aggregation state (register window of e rows, running e pointer)
         int tidm = threadIdx.x;
         asm volatile("" : "+v"(tidm));
         // a register tile contributes only if some (x,d) of it is a candidate the reference evaluates
         // (x - d >= 0, d <= maxDisparity, x < W); waves whose lanes are all outside (left image border,
         // padded disparities) skip the aggregation -- wave-uniform, decided once per window row
-        const int xg_m = tidm % g.XG, dg_m = tidm / g.XG;
-        const bool tile_live = tidm < g.XG * g.DG && x0 + ASW_RX * xg_m < W && dlo + ASW_RD * dg_m <= A.maxD &&
-                               x0 + ASW_RX * xg_m + ASW_RX - 1 - (dlo + ASW_RD * dg_m) >= 0;
-        if (__builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG) {
-            const int xg = xg_m, dg = dg_m;
-            // three running LDS pointers (advanced by one tap column per step) keep the address
-            // arithmetic at ~4 VALU ops per step and nothing step-specific live across the loop
-            const float *wlp = wL + ASW_RX / 2 * xg;                  // even block of the thread's columns; odd block at + hL
-            // right weights: ASW_NWR/4 consecutive 4-float blocks starting at block b0 (parity-split rows)
-            const int b0 = (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD) >> 2;
-            const float *wrp0 = wR + (b0 & 1) * g.hR + ((b0 >> 1) << 2);
-            const float *wrp1 = wR + ((b0 + 1) & 1) * g.hR + (((b0 + 1) >> 1) << 2);
-            const float *wrp2 = wR + (b0 & 1) * g.hR + (((b0 + 2) >> 1) << 2);
-            const unsigned char *erow = eT + (ASW_RX * xg) * Se;
-            // swizzled dword slot of this thread's disparity group: depends on row / RX only, i.e. it
-            // changes once per RX tap columns (rows ul0 .. ul0+RX-1 share slot0)
-            int q = xg;
-            int slotA = (dg ^ (q & emask)) << 2;
-            AswRow ew[ASW_RX];
+        const int xg = tidm % g.XG, dg = tidm / g.XG;
+        const bool tile_live = tidm < g.XG * g.DG && x0 + ASW_RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
+                               x0 + ASW_RX * xg + ASW_RX - 1 - (dlo + ASW_RD * dg) >= 0;
+        const bool run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
+        const unsigned char *erow = eT + (ASW_RX * xg) * Se;
+        // swizzled dword slot of this thread's disparity group: depends on row / RX only, i.e. it
+        // changes once per RX tap columns (rows ul0 .. ul0+RX-1 share slot0)
+        int q = xg;
+        int slotA = (dg ^ (q & emask)) << 2;
+        AswRow ew[ASW_RX];
+
+        for (int jc = 0; jc < win; jc += JC) {
+            const int jend = min(win, jc + JC);
+            const int rb = CHUNKED ? cb * JC : 0;          // first buffer row of this chunk
+            // ---- support weights of window row i, tap columns [jc, jend) (_passive.cpp:47-50 and 71-74;
+            //      exp(-dist/gammaC) = exp2(dist*kC)).  Task = (window centre c, segment of the tap
+            //      columns); consecutive lanes take consecutive centres: conflict-free ds_read_b128 of the
+            //      staged pixels and coalesced LDS writes.  Branch-free: taps or centres outside the image
+            //      get weight 0 through a bit mask.
+            {
+                int tidw = threadIdx.x;
+                asm volatile("" : "+v"(tidw));
+                const float *const prow = proxS + (i & 1) * win;    // proximity weights of window row i, staged in LDS
+                const int ncen = Tx + nRc;
+                for (int t = tidw; t < ncen * g.wseg; t += nthr) {
+                    const int sgm = t / ncen, c = t - sgm * ncen;
+                    const bool isL = c < Tx;
+                    const int cc = isL ? c : c - Tx;
+                    const float4 cen = cenLab[c];                      // centre pixel (row y); .w = inside image
+                    const float4 *const seg = (isL ? labLc : labRc) + cc;
+                    const int stride = isL ? g.SL : SR;
+                    float *const wout = (isL ? wL : wR) + asw_split_pos(cc, isL ? g.hL : g.hR) + (rb - jc) * stride;
+                    const int col0 = (isL ? x0 : xrc_lo) + cc - p;
+                    const int j1 = min(jend, jc + (sgm + 1) * g.wlen);
+                    const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
+                    // batches of ASW_WB independent evaluations: all LDS reads first, then the dependent
+                    // chains (sub, fma, v_sqrt, v_exp, mul) side by side -- a single chain is ~150 cycles of
+                    // latency, and during this phase every wave of the group is in the same loop
+                    for (int j = jc + sgm * g.wlen; j < j1; j += ASW_WB) {
+                        float4 tp[ASW_WB];
+                        float pr[ASW_WB], wv[ASW_WB];
 #pragma unroll
-            for (int n = 0; n < ASW_RX - 1; ++n) {
-                asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow + slotA));
-                erow += Se;
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const int jj = min(j + u, j1 - 1);
+                            tp[u] = seg[jj];
+                            pr[u] = prow[jj];
+                        }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                            wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                        }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
+                            const int jj = min(j + u, j1 - 1);
+                            const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
+                            wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                        }
+                    }
+                }
             }
-            for (int j0 = 0; j0 < win; j0 += ASW_RX) {
-                const int slotB = (dg ^ ((q + 1) & emask)) << 2;
+            __syncthreads();   // e tile and this chunk of wL, wR ready; every thread is done with the previous chunk
+            if (jc == 0 && i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
+
+            // ---- aggregation over the tap columns of this chunk
+            if (run) {
+                if (jc == 0) {
+#pragma unroll
+                    for (int n = 0; n < ASW_RX - 1; ++n) {
+                        asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow + slotA));
+                        erow += Se;
+                    }
+                }
+                // running LDS pointers (advanced by one tap column per step) keep the address arithmetic at
+                // ~4 VALU ops per step and nothing step-specific live across the loop
+                const float *wlp = wL + rb * g.SL + ASW_RX / 2 * xg;      // even block of the thread's columns; odd block at + hL
+                // right weights: ASW_NWR/4 consecutive 4-float blocks starting at block b0 (parity-split rows)
+                const int b0 = (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD) >> 2;
+                const float *wrp0 = wR + rb * SR + (b0 & 1) * g.hR + ((b0 >> 1) << 2);
+                const float *wrp1 = wR + rb * SR + ((b0 + 1) & 1) * g.hR + (((b0 + 1) >> 1) << 2);
+                const float *wrp2 = wR + rb * SR + (b0 & 1) * g.hR + (((b0 + 2) >> 1) << 2);
+                for (int j0 = jc; j0 < jend; j0 += ASW_RX) {
+                    const int slotB = (dg ^ ((q + 1) & emask)) << 2;
 #define SSAMD_STEP(JJ, SLOT)                                                                        \
-    if (j0 + (JJ) < win) {                                                                          \
+    if (j0 + (JJ) < jend) {                                                                         \
         asw_row_unpack(ew[((JJ) + ASW_RX - 1) % ASW_RX], *reinterpret_cast<const uint32_t *>(erow + (SLOT))); \
         erow += Se;                                                                                 \
         float wl[ASW_RX], wr[ASW_NWR];                                                              \
@@ -362,13 +378,15 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         wlp += g.SL; wrp0 += SR; wrp1 += SR; wrp2 += SR;                                            \
         asw_taps<(JJ)>(accN, accS, wl, wr, ew);                                                     \
     }
-                // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards
-                SSAMD_STEP(0, slotA) SSAMD_STEP(1, slotB) SSAMD_STEP(2, slotB) SSAMD_STEP(3, slotB)
-                SSAMD_STEP(4, slotB) SSAMD_STEP(5, slotB) SSAMD_STEP(6, slotB) SSAMD_STEP(7, slotB)
+                    // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards
+                    SSAMD_STEP(0, slotA) SSAMD_STEP(1, slotB) SSAMD_STEP(2, slotB) SSAMD_STEP(3, slotB)
+                    SSAMD_STEP(4, slotB) SSAMD_STEP(5, slotB) SSAMD_STEP(6, slotB) SSAMD_STEP(7, slotB)
 #undef SSAMD_STEP
-                slotA = slotB;
-                ++q;
+                    slotA = slotB;
+                    ++q;
+                }
             }
+            if (CHUNKED) cb ^= 1;
         }
     }
 

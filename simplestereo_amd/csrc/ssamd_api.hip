@@ -173,8 +173,12 @@ int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ ASW geometry
-bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
+bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20)
 {
+    g.JC = JC >= win ? win : JC;                 // tap columns staged per chunk; win = the whole row at once
+    const int wrows = g.JC < win ? 2 * g.JC : win;   // chunk buffers alternate
+    const int wcols = g.JC;                      // tap columns a weight-build pass covers
+
     const int p = win / 2;
     g.XG = XG; g.DG = DG;
     g.Tx = ASW_RX * XG; g.Dc = ASW_RD * DG;
@@ -197,16 +201,16 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit)
     {
         const int ncen = g.Tx + g.nRc;
         int best_cost = 1 << 30;
-        for (int ns = 1; ns <= win && ns <= 8; ++ns) {
-            const int len = (win + ns - 1) / ns, rounds = (ncen * ns + g.threads - 1) / g.threads;
+        for (int ns = 1; ns <= wcols && ns <= 8; ++ns) {
+            const int len = (wcols + ns - 1) / ns, rounds = (ncen * ns + g.threads - 1) / g.threads;
             const int cost = rounds * (round_up(len, ASW_WB) + 2);       // evaluated in batches of ASW_WB
             if (cost < best_cost) { best_cost = cost; g.wseg = ns; g.wlen = len; }
         }
     }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    g.off_wL = take((size_t)win * g.SL * 4);
-    g.off_wR = take((size_t)win * g.SR * 4);
+    g.off_wL = take((size_t)wrows * g.SL * 4);
+    g.off_wR = take((size_t)wrows * g.SR * 4);
     g.off_e = take((size_t)g.nL * g.Se);
     g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
     g.off_labR = take((size_t)g.nR * 16 * 2);
@@ -234,9 +238,10 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
     // tuning hook: SSAMD_ASW_GEOM="XG,DG" forces the tile shape (experiments only)
     if (const char *env = getenv("SSAMD_ASW_GEOM")) {
-        int XG = 0, DG = 0;
-        if (sscanf(env, "%d,%d", &XG, &DG) == 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS) {
-            if (!asw_layout(best, win, XG, DG, 160 * 1024)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
+        int XG = 0, DG = 0, JCe = 1 << 20;
+        if (sscanf(env, "%d,%d,%d", &XG, &DG, &JCe) >= 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS) {
+            if (JCe <= 0 || JCe % ASW_RX) JCe = 1 << 20;
+            if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
             return SSAMD_OK;
         }
@@ -250,16 +255,20 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
         if (DG > 128) continue;
         if ((nD + DG * ASW_RD - 1) / (DG * ASW_RD) != nch) continue;
         const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + ASW_RX - 1) / ASW_RX);
-        for (int XG = xg_cap; XG >= 1; --XG) {
+        for (int XG = xg_cap; XG >= 1; --XG)
+        for (int JC : {1 << 20, 16, 8}) {
+            if (JC < (1 << 20) && JC >= win) continue;
             AswGeom g;
-            if (!asw_layout(g, win, XG, DG, 160 * 1024)) continue;
+            if (!asw_layout(g, win, XG, DG, 160 * 1024, JC)) continue;
             g.nchunks = nch;
             const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
             const int k = std::min(3 / per_simd, (160 * 1024) / g.lds_bytes);
             if (k < 1) continue;
             const double M = (double)win * ASW_RX * ASW_RD * c_tap;
             const int ncen = g.Tx + g.nRc;
-            const double B = (double)((ncen * g.wseg + g.threads - 1) / g.threads) * (g.wlen + 2) * c_w +
+            const int njc = (win + g.JC - 1) / g.JC;                 // weight-build passes (= barriers) per window row
+            const double B = (double)njc * ((ncen * g.wseg + g.threads - 1) / g.threads) * (round_up(g.wlen, ASW_WB) + 2) * c_w +
+                             (njc > 1 ? njc * 400.0 : 0.0) +               // extra barriers of the chunked form
                              (double)((g.nL * (g.Dc / 4) + g.threads - 1) / g.threads) * c_e +
                              (double)((g.nL + g.nR + g.threads - 1) / g.threads) * c_stage;
             const double d_util = (double)nD / ((double)nch * g.Dc);
@@ -361,7 +370,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
         const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, rows, a.g.nchunks), block(a.g.threads);
-        auto kern = d_costs ? asw_aggregate_kernel<true> : asw_aggregate_kernel<false>;
+        const bool chunked = a.g.JC < win;
+        auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
+                            : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.g.lds_bytes));
         {
             Timed t(c, s, SSAMD_K_ASW_AGG);
