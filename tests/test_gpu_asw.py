@@ -141,3 +141,19 @@ def test_asw_degenerate_ranges(ss, golden_inputs):
     flat = np.full((12, 50, 3), 77, np.uint8)      # all costs exactly 0: ties -> smallest disparity
     p = dict(winSize=7, maxDisparity=9, minDisparity=2)
     assert np.array_equal(ss.passive.StereoASW(**p).compute(flat, flat), oracle.asw(flat, flat, **p))
+
+
+@pytest.mark.parametrize("geom", ["6,5,8", "10,9,16", "3,9,8", "12,3,8"])
+def test_asw_forced_geometries_and_chunked_staging_agree(geom, ss, golden_inputs):
+    """every launch geometry (tile shape, tap-column chunking) computes the same sums in the same order:
+    forced shapes via the SSAMD_ASW_GEOM tuning hook must reproduce the default result bit for bit"""
+    a, b = golden_inputs("synth_96x128")
+    maxd = int(geom.split(",")[1]) * 4 - 1
+    m = ss.passive.StereoASW(winSize=21, maxDisparity=maxd, minDisparity=0, consistent=True)
+    want = m.compute(a, b)
+    os.environ["SSAMD_ASW_GEOM"] = geom
+    try:
+        got = m.compute(a, b)
+    finally:
+        del os.environ["SSAMD_ASW_GEOM"]
+    assert np.array_equal(got, want)
