@@ -138,6 +138,10 @@ const char *ssamd_kernel_name(int slot);
  * out[0..7] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y, grid_z */
 int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
 
+/* Same for a GSW problem; out[0..8] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y,
+ * grid_z, strip_rows (output rows per workgroup: 1 or 2) */
+int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ def lib():
     L.ssamd_kernel_name.argtypes = [I]
     L.ssamd_asw_geometry.restype = I
     L.ssamd_asw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
+    L.ssamd_gsw_geometry.restype = I
+    L.ssamd_gsw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
     if L.ssamd_abi_version() != 1:
         raise ImportError("libssamd ABI version mismatch")
     _lib = L
@@ -89,4 +91,11 @@ def asw_geometry(width, rows, winSize, maxDisparity, minDisparity):
     out = (ctypes.c_int * 8)()
     check(lib().ssamd_asw_geometry(width, rows, winSize, maxDisparity, minDisparity, out))
     keys = ("tile_x", "chunk_d", "n_chunks", "threads", "lds_bytes", "grid_x", "grid_y", "grid_z")
+    return dict(zip(keys, list(out)))
+
+
+def gsw_geometry(width, rows, winSize, maxDisparity, minDisparity):
+    out = (ctypes.c_int * 9)()
+    check(lib().ssamd_gsw_geometry(width, rows, winSize, maxDisparity, minDisparity, out))
+    keys = ("tile_x", "chunk_d", "n_chunks", "threads", "lds_bytes", "grid_x", "grid_y", "grid_z", "strip_rows")
     return dict(zip(keys, list(out)))

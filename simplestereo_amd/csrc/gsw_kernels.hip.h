@@ -18,21 +18,25 @@
 //   * the same kernel serves both passes: reference image / target image swap roles and the
 //     target column is ref_col - d (left-referenced) or ref_col + d (right-referenced).
 //
-// Work decomposition mirrors the ASW kernel: workgroup = (row y, tile of Tx reference
-// columns, chunk of Dc disparities); thread = 4 columns x 8 disparities; per window row the
-// group builds w[j][x] and e[u][d] (fp32) in LDS; e rows slide through registers.
+// Work decomposition mirrors the ASW kernel: workgroup = (TY consecutive output rows, tile of Tx
+// reference columns, chunk of Dc disparities); thread = TY rows x 4 columns x RD disparities.  Per IMAGE
+// row the group builds e[u][d] (fp32) once in LDS and the support weights w[t][j][x] of each of its
+// output rows; e rows slide through registers and feed the accumulators of all TY output rows.  The
+// e tile is the expensive part (a correctly rounded sqrt per element), and an image row serves
+// up to win window rows of different outputs: TY = 2 halves the number of times it is rebuilt.  The
+// two instantiated tiles, (TY, RD) = (1, 8) and (2, 4), have the same accumulator count (32) and the
+// same LDS read volume per tap (three 16-byte reads per 32 multiply-add pairs).
 #pragma once
 #include "common.hip.h"
 
 namespace ssamd {
 
 static constexpr int GSW_RX = 4;
-static constexpr int GSW_RD = 8;
 static constexpr int GSW_MAX_THREADS = 512;
 static constexpr int GSW_TAB_SIZE = 3 * 255 * 255 + 1;
 
 struct GswGeom {
-    int Tx, XG, DG, Dc, nchunks, threads;
+    int Tx, XG, DG, Dc, nchunks, threads, Ty, Rd;   // thread tile: Ty output rows x 4 columns x Rd disparities
     int nL, nT, Se, emask;          // Se: floats per e row (32-byte slots, XOR-swizzled)
     int off_w, off_e, off_ref, off_tgt, off_best;
     int lds_bytes;
@@ -87,13 +91,15 @@ __device__ __forceinline__ int gsw_e_offset(int ul, int slot, int Se, int emask)
     return ul * Se + ((slot ^ ((ul >> 2) & emask)) << 3);     // in floats; slot = 8 floats
 }
 
-// 32 taps of one tap column: cost = fl(cost + fl(w * e)), no contraction (reference is -O2 x86-64)
-__device__ __forceinline__ void gsw_taps(float (&cost)[GSW_RX][GSW_RD], const float4 w4, const float (&r0)[GSW_RD],
-                                         const float (&r1)[GSW_RD], const float (&r2)[GSW_RD], const float (&r3)[GSW_RD])
+// 4 x RD taps of one tap column for one output row: cost = fl(cost + fl(w * e)), no contraction
+// (the reference is -O2 x86-64 without FMA)
+template <int RD>
+__device__ __forceinline__ void gsw_taps(float (&cost)[GSW_RX][RD], const float4 w4, const float (&r0)[RD],
+                                         const float (&r1)[RD], const float (&r2)[RD], const float (&r3)[RD])
 {
 #pragma clang fp contract(off)
 #pragma unroll
-    for (int di = 0; di < GSW_RD; ++di) {
+    for (int di = 0; di < RD; ++di) {
         cost[0][di] = cost[0][di] + w4.x * r0[di];
         cost[1][di] = cost[1][di] + w4.y * r1[di];
         cost[2][di] = cost[2][di] + w4.z * r2[di];
@@ -101,29 +107,70 @@ __device__ __forceinline__ void gsw_taps(float (&cost)[GSW_RX][GSW_RD], const fl
     }
 }
 
-__device__ __forceinline__ void gsw_load_row(float (&row)[GSW_RD], const float *e, int off)
+// RD consecutive disparities of e row ul; dg = index of the thread's disparity group (RD = 8: one
+// 32-byte slot, RD = 4: half a slot)
+template <int RD>
+__device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e, int ul, int dg, int Se, int emask)
 {
-    const float4 a = *reinterpret_cast<const float4 *>(e + off);
-    const float4 b = *reinterpret_cast<const float4 *>(e + off + 4);
-    row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
-    row[4] = b.x; row[5] = b.y; row[6] = b.z; row[7] = b.w;
+    static_assert(RD == 4 || RD == 8, "thread tiles of 4 or 8 disparities");
+    if constexpr (RD == 8) {
+        const int off = gsw_e_offset(ul, dg, Se, emask);
+        const float4 a = *reinterpret_cast<const float4 *>(e + off);
+        const float4 b = *reinterpret_cast<const float4 *>(e + off + 4);
+        row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
+        row[4] = b.x; row[5] = b.y; row[6] = b.z; row[7] = b.w;
+    } else {
+        const float4 a = *reinterpret_cast<const float4 *>(e + gsw_e_offset(ul, dg >> 1, Se, emask) + 4 * (dg & 1));
+        row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
+    }
 }
 
-__global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const GswArgs A)
+// All tap columns of the current image row for output rows [T0, T1) of the strip.  The e rows slide
+// through four register rows (one new row per tap column) and are shared by the output rows.
+template <int TY, int RD, int T0, int T1>
+__device__ __forceinline__ void gsw_row_taps(float (&cost)[TY][GSW_RX][RD], const float *wS, const float *eT, int win,
+                                             int Tx, int xg, int dg, int Se, int emask)
+{
+    const float *wp = wS + GSW_RX * xg;
+    const int ul0 = GSW_RX * xg, wstride = win * Tx;
+#define SSAMD_GROW(dst, n) gsw_load_row<RD>(dst, eT, ul0 + (n), dg, Se, emask)
+#define SSAMD_GSTEP(j, ra, rb, rc, rd)                                                                        \
+    if ((j) < win) {                                                                                          \
+        SSAMD_GROW(rd, (j) + 3);                                                                              \
+        _Pragma("unroll") for (int t = T0; t < T1; ++t)                                                       \
+            gsw_taps<RD>(cost[t], *reinterpret_cast<const float4 *>(wp + t * wstride + (j) * Tx), ra, rb, rc, rd); \
+    }
+    float e0[RD], e1[RD], e2[RD], e3[RD];
+    SSAMD_GROW(e0, 0);
+    SSAMD_GROW(e1, 1);
+    SSAMD_GROW(e2, 2);
+    for (int j0 = 0; j0 < win; j0 += 4) {
+        SSAMD_GSTEP(j0, e0, e1, e2, e3)
+        SSAMD_GSTEP(j0 + 1, e1, e2, e3, e0)
+        SSAMD_GSTEP(j0 + 2, e2, e3, e0, e1)
+        SSAMD_GSTEP(j0 + 3, e3, e0, e1, e2)
+    }
+#undef SSAMD_GSTEP
+#undef SSAMD_GROW
+}
+
+template <int TY, int RD>
+__global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const GswArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GswGeom &g = A.g;
-    float *const wS = reinterpret_cast<float *>(smem + g.off_w);          // [win][Tx]
+    float *const wS = reinterpret_cast<float *>(smem + g.off_w);          // [TY][win][Tx]
     float *const eT = reinterpret_cast<float *>(smem + g.off_e);          // [nL][Se]
     float4 *const refS = reinterpret_cast<float4 *>(smem + g.off_ref);    // [nL] {b, g, r, inside image}
     float4 *const tgtS = reinterpret_cast<float4 *>(smem + g.off_tgt);    // [nT]
-    u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [Tx]
+    u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [TY][Tx]
 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int W = A.W, H = A.H, win = A.win, p = A.pad;
     const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nT = g.nT, Se = g.Se, emask = g.emask;
     const int x0 = blockIdx.x * Tx;
-    const int y = A.row0 + blockIdx.y;
+    const int y0 = A.row0 + blockIdx.y * TY;                     // first output row of the strip
+    const int ny = min(TY, A.row0 + A.rows - y0);                // output rows of the strip that exist
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
     const bool right = A.right != 0;
@@ -137,17 +184,19 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
     const bool active = tid < g.XG * g.DG;
     const int xg = tid % g.XG, dg = tid / g.XG;
 
-    float cost[GSW_RX][GSW_RD];
+    float cost[TY][GSW_RX][RD];
 #pragma unroll
-    for (int a = 0; a < GSW_RX; ++a)
+    for (int t = 0; t < TY; ++t)
 #pragma unroll
-        for (int b = 0; b < GSW_RD; ++b) cost[a][b] = 0.f;
-    for (int k = tid; k < Tx; k += nthr) best[k] = KEY_NONE;
+        for (int a = 0; a < GSW_RX; ++a)
+#pragma unroll
+            for (int b = 0; b < RD; ++b) cost[t][a][b] = 0.f;
+    for (int k = tid; k < TY * Tx; k += nthr) best[k] = KEY_NONE;
 
-    const int i_lo = max(0, p - y), i_hi = min(win, H + p - y);
-    for (int i = i_lo; i < i_hi; ++i) {
-        const int r = y - p + i;
-        __syncthreads();                    // previous window row fully consumed
+    // image rows in ascending order: every output row sees its window rows in the reference's raster order
+    const int r_lo = max(0, y0 - p), r_hi = min(H - 1, y0 + ny - 1 + p);
+    for (int r = r_lo; r <= r_hi; ++r) {
+        __syncthreads();                    // previous image row fully consumed
         for (int k = tid; k < nL + nT; k += nthr) {     // staged pixels as floats: converted once per pixel,
             const bool isRef = k < nL;                   // not once per (pixel, disparity) element
             const int idx = isRef ? k : k - nL;
@@ -158,29 +207,38 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
         }
         __syncthreads();
 
-        // ---- support weights of window row i for the tile's reference pixels
-        for (int t = tid; t < Tx * win; t += nthr) {
-            const int j = t / Tx, c = t - j * Tx;
-            const int x = x0 + c, col = x - p + j;
-            float w = 0.f;
-            if (x < W && (unsigned)col < (unsigned)W) {
-                const bool centre = (i == p) && (j == p);
-                bool reached = A.iterations > 0;
-                if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
-                if (centre) w = 1.0f;                                                   // exp(-0/gamma)
-                else if (reached) {
-                    const float4 cpx = bgr_unpack(A.ref[(size_t)y * W + x], 1.f);
-                    w = A.tab[(int)bgr_dist2f(refS[c + j], cpx)];
+        // ---- support weights of this image row for the tile's reference pixels, per output row:
+        //      image row r is window row i = r - y + pad of output row y
+        bool use[TY];
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+            const int y = y0 + t, i = r - y + p;
+            use[t] = t < ny && (unsigned)i < (unsigned)win;
+            if (!use[t]) continue;
+            float *const wT = wS + t * win * Tx;
+            for (int k = tid; k < Tx * win; k += nthr) {
+                const int j = k / Tx, c = k - j * Tx;
+                const int x = x0 + c, col = x - p + j;
+                float w = 0.f;
+                if (x < W && (unsigned)col < (unsigned)W) {
+                    const bool centre = (i == p) && (j == p);
+                    bool reached = A.iterations > 0;
+                    if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
+                    if (centre) w = 1.0f;                                                   // exp(-0/gamma)
+                    else if (reached) {
+                        const float4 cpx = bgr_unpack(A.ref[(size_t)y * W + x], 1.f);
+                        w = A.tab[(int)bgr_dist2f(refS[c + j], cpx)];
+                    }
                 }
+                wT[k] = w;
             }
-            wS[j * Tx + c] = w;
         }
         // ---- e[ul][d] = min(fMax, ||ref(r,u) - tgt(r,u -/+ d)||), 0 when the target column is outside.
-        //      Task index (column ul fastest, then disparity) advanced without divisions.
         //      Task = (column ul, disparity dd) with dd fastest across the lanes of a wave: the e writes of
         //      a wave then fall into consecutive floats (the column-fastest order put 64 lanes on 4 banks),
         //      the reference pixel is a broadcast read and the target pixels are consecutive 16-byte reads.
-        //      Four independent elements per iteration (LDS reads first, then the sub/fma/sqrt chains).
+        //      Task index advanced without divisions; four independent elements per iteration (LDS reads
+        //      first, then the sub/fma/sqrt chains).
         {
             const int e_q = nthr / Dc, e_r = nthr - e_q * Dc;
             int ul = tid / Dc, dd = tid - ul * Dc;
@@ -212,26 +270,14 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
         __syncthreads();
 
         if (active) {
-            const float *wp = wS + GSW_RX * xg;
-            const int ul0 = GSW_RX * xg;
-#define SSAMD_GROW(dst, n) gsw_load_row(dst, eT, gsw_e_offset(ul0 + (n), dg, Se, emask))
-#define SSAMD_GSTEP(j, ra, rb, rc, rd)                                                       \
-    if ((j) < win) {                                                                         \
-        SSAMD_GROW(rd, (j) + 3);                                                             \
-        gsw_taps(cost, *reinterpret_cast<const float4 *>(wp + (j) * Tx), ra, rb, rc, rd);    \
-    }
-            float e0[GSW_RD], e1[GSW_RD], e2[GSW_RD], e3[GSW_RD];
-            SSAMD_GROW(e0, 0);
-            SSAMD_GROW(e1, 1);
-            SSAMD_GROW(e2, 2);
-            for (int j0 = 0; j0 < win; j0 += 4) {
-                SSAMD_GSTEP(j0, e0, e1, e2, e3)
-                SSAMD_GSTEP(j0 + 1, e1, e2, e3, e0)
-                SSAMD_GSTEP(j0 + 2, e2, e3, e0, e1)
-                SSAMD_GSTEP(j0 + 3, e3, e0, e1, e2)
+            if constexpr (TY == 1) {
+                gsw_row_taps<1, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
+            } else {
+                static_assert(TY == 2, "strips of 1 or 2 output rows");
+                if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
+                else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
+                else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
             }
-#undef SSAMD_GSTEP
-#undef SSAMD_GROW
         }
     }
 
@@ -239,23 +285,27 @@ __global__ __launch_bounds__(GSW_MAX_THREADS) void gsw_aggregate_kernel(const Gs
     //      _passive.cpp:538-541 / 654-657), then merge across chunks with a global atomic
     if (active) {
 #pragma unroll
-        for (int xi = 0; xi < GSW_RX; ++xi) {
-            const int x = x0 + GSW_RX * xg + xi;
-            u64 b = KEY_NONE;
+        for (int t = 0; t < TY; ++t) {
+            if (t >= ny) continue;
 #pragma unroll
-            for (int di = 0; di < GSW_RD; ++di) {
-                const int d = dlo + GSW_RD * dg + di;
-                const bool valid = (x < W) && (d <= A.maxD) && (right ? (x + d <= W - 1) : (x - d >= 0));
-                if (valid) b = min(b, make_key(cost[xi][di], right ? (uint32_t)(x + d) : (uint32_t)d));
+            for (int xi = 0; xi < GSW_RX; ++xi) {
+                const int x = x0 + GSW_RX * xg + xi;
+                u64 b = KEY_NONE;
+#pragma unroll
+                for (int di = 0; di < RD; ++di) {
+                    const int d = dlo + RD * dg + di;
+                    const bool valid = (x < W) && (d <= A.maxD) && (right ? (x + d <= W - 1) : (x - d >= 0));
+                    if (valid) b = min(b, make_key(cost[t][xi][di], right ? (uint32_t)(x + d) : (uint32_t)d));
+                }
+                if (b != KEY_NONE) atomicMin(&best[t * Tx + GSW_RX * xg + xi], b);
             }
-            if (b != KEY_NONE) atomicMin(&best[GSW_RX * xg + xi], b);
         }
     }
     __syncthreads();
-    const size_t orow = (size_t)(y - A.row0) * W;
-    for (int k = tid; k < Tx; k += nthr) {
-        const int x = x0 + k;
-        if (x < W && best[k] != KEY_NONE) atomicMin(&A.key[orow + x], best[k]);
+    for (int k = tid; k < ny * Tx; k += nthr) {
+        const int t = k / Tx, c = k - t * Tx;
+        const int x = x0 + c;
+        if (x < W && best[k] != KEY_NONE) atomicMin(&A.key[(size_t)(y0 + t - A.row0) * W + x], best[k]);
     }
 }
 

@@ -385,59 +385,78 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
 
 
 // ------------------------------------------------------------ GSW
-bool gsw_layout(GswGeom &g, int win, int XG, int DG, size_t limit)
+bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
 {
     const int p = win / 2;
-    g.XG = XG; g.DG = DG;
-    g.Tx = GSW_RX * XG; g.Dc = GSW_RD * DG;
+    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = Ty == 2 ? 4 : 8;
+    g.Tx = GSW_RX * XG; g.Dc = g.Rd * DG;
     g.threads = round_up(XG * DG, 64);
     g.nL = g.Tx + 2 * p;
     g.nT = g.nL + g.Dc - 1;
     int P = 1;
-    while (P < DG) P <<= 1;
-    g.Se = 8 * P;                                  // floats per e row
+    while (8 * P < g.Dc) P <<= 1;
+    g.Se = 8 * P;                                  // floats per e row (slots of 8 disparities)
     g.emask = std::min(P, 32) - 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    g.off_w = take((size_t)win * g.Tx * 4);
+    g.off_w = take((size_t)Ty * win * g.Tx * 4);
     g.off_e = take((size_t)g.nL * g.Se * 4);
     g.off_ref = take((size_t)g.nL * 16);
     g.off_tgt = take((size_t)g.nT * 16);
-    g.off_best = take((size_t)g.Tx * 8);
+    g.off_best = take((size_t)Ty * g.Tx * 8);
     g.lds_bytes = (int)off;
     return off <= limit;
 }
 
+// Launch geometry of the GSW kernel: strip height Ty, XG x DG thread grid.  Relative cost model of one
+// strip, per thread: every image row of the strip pays the e tile once (c_e per element), every
+// (output row, window row) pair pays its weights (c_w per element) and its taps (c_tap per cell).
 int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)
 {
+    if (const char *env = getenv("SSAMD_GSW_GEOM")) {           // experiment hook: "XG,DG,Ty"
+        int XG = 0, DG = 0, Ty = 1;
+        if (sscanf(env, "%d,%d,%d", &XG, &DG, &Ty) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) &&
+            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024)) {
+            best.nchunks = (nD + best.Dc - 1) / best.Dc;
+            return SSAMD_OK;
+        }
+        return fail(SSAMD_EINVAL, "SSAMD_GSW_GEOM=%s is not a usable geometry", env);
+    }
     const double c_tap = 5.3, c_w = 60.0, c_e = 70.0;
     double best_score = -1.0;
     bool found = false;
-    for (int nch = 1; nch <= nD; ++nch) {
-        const int per = (nD + nch - 1) / nch;
-        const int DG = round_up(per, GSW_RD) / GSW_RD;
-        if (DG > 64) continue;
-        if ((nD + DG * GSW_RD - 1) / (DG * GSW_RD) != nch) continue;
-        const int xg_cap = std::min(GSW_MAX_THREADS / DG, (W + GSW_RX - 1) / GSW_RX);
-        for (int XG = xg_cap; XG >= 1; --XG) {
-            GswGeom g;
-            if (!gsw_layout(g, win, XG, DG, 160 * 1024)) continue;
-            g.nchunks = nch;
-            const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
-            const int k = std::min({4 / per_simd, (160 * 1024) / g.lds_bytes, 8});   // 98 VGPRs -> 4 waves per SIMD
-            if (k < 1) continue;
-            const double M = (double)win * GSW_RX * GSW_RD * c_tap;
-            const double B = (double)((g.Tx * win + g.threads - 1) / g.threads) * c_w +
-                             (double)((g.nL * g.Dc + g.threads - 1) / g.threads) * c_e;
-            const double d_util = (double)nD / ((double)nch * g.Dc);
-            const int xt = (W + g.Tx - 1) / g.Tx;
-            const double x_util = (double)W / ((double)xt * g.Tx);
-            const double nwg = (double)xt * std::max(rows, 1) * nch, slots = 256.0 * k;
-            const double tail = nwg / (std::ceil(nwg / slots) * slots);
-            const double score = (double)k * XG * DG * (M / (M + B)) * d_util * x_util * tail;
-            if (score > best_score) { best_score = score; best = g; found = true; }
+    for (int Ty = 1; Ty <= 2; ++Ty) {
+        if (Ty > std::max(rows, 1)) break;
+        const int Rd = Ty == 2 ? 4 : 8;
+        for (int nch = 1; nch <= nD; ++nch) {
+            const int per = (nD + nch - 1) / nch;
+            const int DG = round_up(per, Rd) / Rd;
+            if (DG > 64) continue;
+            if ((nD + DG * Rd - 1) / (DG * Rd) != nch) continue;
+            const int xg_cap = std::min(GSW_MAX_THREADS / DG, (W + GSW_RX - 1) / GSW_RX);
+            for (int XG = xg_cap; XG >= 1; --XG) {
+                GswGeom g;
+                if (!gsw_layout(g, win, XG, DG, Ty, 160 * 1024)) continue;
+                g.nchunks = nch;
+                const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
+                const int k = std::min({4 / per_simd, (160 * 1024) / g.lds_bytes, 8});   // <= 128 VGPRs: 4 waves per SIMD
+                if (k < 1) continue;
+                const double M = (double)win * GSW_RX * Rd * c_tap;
+                const double Bw = (double)((g.Tx * win + g.threads - 1) / g.threads) * c_w;
+                const double Be = (double)((g.nL * g.Dc + g.threads - 1) / g.threads) * c_e;
+                const double strip = (double)(win + Ty - 1) * Be + (double)Ty * win * (M + Bw);
+                const double eff = (double)Ty * win * M / strip;
+                const double d_util = (double)nD / ((double)nch * g.Dc);
+                const int xt = (W + g.Tx - 1) / g.Tx, yt = (std::max(rows, 1) + Ty - 1) / Ty;
+                const double x_util = (double)W / ((double)xt * g.Tx);
+                const double y_util = (double)std::max(rows, 1) / ((double)yt * Ty);
+                const double nwg = (double)xt * yt * nch, slots = 256.0 * k;
+                const double tail = nwg / (std::ceil(nwg / slots) * slots);
+                const double score = (double)k * XG * DG * eff * d_util * x_util * y_util * tail;
+                if (score > best_score) { best_score = score; best = g; found = true; }
+            }
+            if (DG <= 1) break;
         }
-        if (DG <= 1) break;
     }
     return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no GSW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
 }
@@ -493,16 +512,16 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.tab = (const float *)c.gswTab.ptr;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.iterations = iterations; a.fMax = fMax;
-        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, rows, a.g.nchunks), block(a.g.threads);
-        HIP_TRY(hipFuncSetAttribute((const void *)gsw_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    a.g.lds_bytes));
+        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + a.g.Ty - 1) / a.g.Ty, a.g.nchunks), block(a.g.threads);
+        auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, a.g.lds_bytes));
         for (int pass = 0; pass < 2; ++pass) {
             a.right = pass;
             a.ref = (const uint32_t *)(pass ? c.recR.ptr : c.recL.ptr);
             a.tgt = (const uint32_t *)(pass ? c.recL.ptr : c.recR.ptr);
             a.key = (u64 *)(pass ? c.keyR.ptr : c.keyL.ptr);
             Timed t(c, s, SSAMD_K_GSW_AGG);
-            hipLaunchKernelGGL(gsw_aggregate_kernel, grid, block, a.g.lds_bytes, s, a);
+            hipLaunchKernelGGL(kernel, grid, block, a.g.lds_bytes, s, a);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -543,6 +562,21 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
     if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
     out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
     out[5] = (width + g.Tx - 1) / g.Tx; out[6] = rows; out[7] = g.nchunks;
+    return SSAMD_OK;
+}
+
+int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!out) return fail(SSAMD_EINVAL, "out is NULL");
+    int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
+    if (rc) return rc;
+    const int nD = maxDisparity - minDisparity + 1;
+    if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
+    GswGeom g;
+    if ((rc = gsw_choose_geometry(g, width, rows, winSize, nD))) return rc;
+    out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
+    out[5] = (width + g.Tx - 1) / g.Tx; out[6] = (rows + g.Ty - 1) / g.Ty; out[7] = g.nchunks; out[8] = g.Ty;
     return SSAMD_OK;
 }
 

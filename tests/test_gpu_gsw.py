@@ -109,3 +109,24 @@ def test_gsw_integer_sqrt_is_exact_over_whole_domain(ss):
     _native.check(_native.lib().ssamd_debug_gsw_sqrt(n, out.ctypes.data))
     want = np.sqrt(np.arange(n, dtype=np.float64)).astype(np.float32)
     assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("geom", ["8,4,1", "8,4,2", "5,3,2", "16,2,1", "3,7,2"])
+def test_gsw_forced_geometries_and_strip_heights_agree(geom, ss, golden_cases, golden_inputs):
+    """one- and two-row strips, and every tile shape, accumulate each output row's taps in the reference's
+    raster order: forced shapes via the SSAMD_GSW_GEOM tuning hook reproduce the reference bit for bit
+    (odd image heights leave a half-filled last strip)"""
+    maps, _ = golden_cases
+    a, b = golden_inputs("synth_64x96")
+    m = ss.passive.StereoGSW(winSize=11, maxDisparity=24, minDisparity=0)
+    base = m.compute(a, b)
+    odd = m.compute(np.ascontiguousarray(a[:37]), np.ascontiguousarray(b[:37]))
+    os.environ["SSAMD_GSW_GEOM"] = geom
+    try:
+        got = m.compute(a, b)
+        got_odd = m.compute(np.ascontiguousarray(a[:37]), np.ascontiguousarray(b[:37]))
+    finally:
+        del os.environ["SSAMD_GSW_GEOM"]
+    assert np.array_equal(got, base)
+    assert np.array_equal(got_odd, odd)
+    assert np.array_equal(got, maps["G6d"])     # G6d = these parameters on this pair, from the reference
