@@ -37,7 +37,7 @@ static constexpr int GSW_TAB_SIZE = 3 * 255 * 255 + 1;
 
 struct GswGeom {
     int Tx, XG, DG, Dc, nchunks, threads, Ty, Rd;   // thread tile: Ty output rows x 4 columns x Rd disparities
-    int nL, nT, Se, emask;          // Se: floats per e row (32-byte slots, XOR-swizzled)
+    int nL, nT, Se, emask, Ses;     // Se = 1 << Ses: floats per e row (32-byte slots, XOR-swizzled)
     int off_w, off_e, off_ref, off_tgt, off_best;
     int lds_bytes;
 };
@@ -53,42 +53,40 @@ struct GswArgs {
     GswGeom g;
 };
 
-// fl32(sqrt(s)) for an INTEGER-valued s in [0, 3*255^2]: v_sqrt_f32 (1 ulp) followed by one
-// Newton step on the exact fma residual.  Equal to the reference's (float)sqrt((double)s) for every
+// fl32(sqrt(s)) for an INTEGER-valued s in [0, 3*255^2]: r = s * v_rsq_f32(s) (about 1.5 ulp) followed
+// by one Newton step on the exact fma residual.  Equal to the reference's (float)sqrt((double)s) for every
 // such s -- checked exhaustively on the device by tests/test_gpu_gsw.py through ssamd_debug_gsw_sqrt --
-// at a third of the instructions of the general correctly-rounded sqrtf expansion.
+// at a quarter of the instructions of the general correctly-rounded sqrtf expansion.  The clamp keeps
+// s = 0 finite: r = 0 * rsq(tiny) = 0, residual 0, result 0.
 __device__ __forceinline__ float gsw_sqrt_int(float s)
 {
-    const float r = __builtin_amdgcn_sqrtf(s);
-    const float h = 0.5f * __builtin_amdgcn_rcpf(r);
+    const float y = __builtin_amdgcn_rsqf(fmaxf(s, 1e-30f));
+    const float r = s * y, h = 0.5f * y;
     const float e = fmaf(-r, r, s);
-    const float r1 = fmaf(e, h, r);
-    return s > 0.f ? r1 : 0.f;
+    return fmaf(e, h, r);
 }
 
-__device__ __forceinline__ float4 bgr_unpack(uint32_t v, float valid)
+// A staged pixel: packed colour bytes (B | G<<8 | R<<16), their squared norm, and 1.0f / 0.0f for
+// inside / outside the image.
+struct alignas(16) GswPix {
+    uint32_t bgr, norm;
+    float inside, pad;
+};
+
+__device__ __forceinline__ GswPix gsw_pix(uint32_t v, float inside)
 {
-    return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), valid);
+    return GswPix{v, __builtin_amdgcn_udot4(v, v, 0u, false), inside, 0.f};
 }
 
-__device__ __forceinline__ float bgr_dist2f(const float4 a, const float4 b)
+// |a - b|^2 over the three colour bytes = |a|^2 + |b|^2 - 2 a.b, in integers (one v_dot4_u32_u8)
+__device__ __forceinline__ uint32_t gsw_dist2(const GswPix a, const GswPix b)
 {
-    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z;
-    return d0 * d0 + d1 * d1 + d2 * d2;       // integers < 2^24: exact in fp32 whatever the contraction
+    return a.norm + b.norm - 2u * __builtin_amdgcn_udot4(a.bgr, b.bgr, 0u, false);
 }
 
-// |a-b|^2 over the three colour bytes, exact in fp32
-__device__ __forceinline__ float bgr_dist2(uint32_t a, uint32_t b)
+__device__ __forceinline__ int gsw_e_offset(int ul, int slot, int Ses, int emask)
 {
-    const float d0 = (float)(a & 0xffu) - (float)(b & 0xffu);
-    const float d1 = (float)((a >> 8) & 0xffu) - (float)((b >> 8) & 0xffu);
-    const float d2 = (float)((a >> 16) & 0xffu) - (float)((b >> 16) & 0xffu);
-    return d0 * d0 + d1 * d1 + d2 * d2;
-}
-
-__device__ __forceinline__ int gsw_e_offset(int ul, int slot, int Se, int emask)
-{
-    return ul * Se + ((slot ^ ((ul >> 2) & emask)) << 3);     // in floats; slot = 8 floats
+    return (ul << Ses) + ((slot ^ ((ul >> 2) & emask)) << 3);     // in floats; slot = 8 floats
 }
 
 // 4 x RD taps of one tap column for one output row: cost = fl(cost + fl(w * e)), no contraction
@@ -110,17 +108,17 @@ __device__ __forceinline__ void gsw_taps(float (&cost)[GSW_RX][RD], const float4
 // RD consecutive disparities of e row ul; dg = index of the thread's disparity group (RD = 8: one
 // 32-byte slot, RD = 4: half a slot)
 template <int RD>
-__device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e, int ul, int dg, int Se, int emask)
+__device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e, int ul, int dg, int Ses, int emask)
 {
     static_assert(RD == 4 || RD == 8, "thread tiles of 4 or 8 disparities");
     if constexpr (RD == 8) {
-        const int off = gsw_e_offset(ul, dg, Se, emask);
+        const int off = gsw_e_offset(ul, dg, Ses, emask);
         const float4 a = *reinterpret_cast<const float4 *>(e + off);
         const float4 b = *reinterpret_cast<const float4 *>(e + off + 4);
         row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
         row[4] = b.x; row[5] = b.y; row[6] = b.z; row[7] = b.w;
     } else {
-        const float4 a = *reinterpret_cast<const float4 *>(e + gsw_e_offset(ul, dg >> 1, Se, emask) + 4 * (dg & 1));
+        const float4 a = *reinterpret_cast<const float4 *>(e + gsw_e_offset(ul, dg >> 1, Ses, emask) + 4 * (dg & 1));
         row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
     }
 }
@@ -129,11 +127,11 @@ __device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e, i
 // through four register rows (one new row per tap column) and are shared by the output rows.
 template <int TY, int RD, int T0, int T1>
 __device__ __forceinline__ void gsw_row_taps(float (&cost)[TY][GSW_RX][RD], const float *wS, const float *eT, int win,
-                                             int Tx, int xg, int dg, int Se, int emask)
+                                             int Tx, int xg, int dg, int Ses, int emask)
 {
     const float *wp = wS + GSW_RX * xg;
     const int ul0 = GSW_RX * xg, wstride = win * Tx;
-#define SSAMD_GROW(dst, n) gsw_load_row<RD>(dst, eT, ul0 + (n), dg, Se, emask)
+#define SSAMD_GROW(dst, n) gsw_load_row<RD>(dst, eT, ul0 + (n), dg, Ses, emask)
 #define SSAMD_GSTEP(j, ra, rb, rc, rd)                                                                        \
     if ((j) < win) {                                                                                          \
         SSAMD_GROW(rd, (j) + 3);                                                                              \
@@ -161,13 +159,14 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     const GswGeom &g = A.g;
     float *const wS = reinterpret_cast<float *>(smem + g.off_w);          // [TY][win][Tx]
     float *const eT = reinterpret_cast<float *>(smem + g.off_e);          // [nL][Se]
-    float4 *const refS = reinterpret_cast<float4 *>(smem + g.off_ref);    // [nL] {b, g, r, inside image}
-    float4 *const tgtS = reinterpret_cast<float4 *>(smem + g.off_tgt);    // [nT]
+    GswPix *const refS = reinterpret_cast<GswPix *>(smem + g.off_ref);    // [nL]
+    GswPix *const tgtS = reinterpret_cast<GswPix *>(smem + g.off_tgt);    // [nT]
     u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [TY][Tx]
 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int W = A.W, H = A.H, win = A.win, p = A.pad;
-    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nT = g.nT, Se = g.Se, emask = g.emask;
+    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nT = g.nT, Ses = g.Ses, emask = g.emask;
+    const int nL4 = (nL + 3) & ~3, nT4 = nT + (nL4 - nL);      // staged columns, padded for the 4-column e tasks
     const int x0 = blockIdx.x * Tx;
     const int y0 = A.row0 + blockIdx.y * TY;                     // first output row of the strip
     const int ny = min(TY, A.row0 + A.rows - y0);                // output rows of the strip that exist
@@ -197,86 +196,90 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     const int r_lo = max(0, y0 - p), r_hi = min(H - 1, y0 + ny - 1 + p);
     for (int r = r_lo; r <= r_hi; ++r) {
         __syncthreads();                    // previous image row fully consumed
-        for (int k = tid; k < nL + nT; k += nthr) {     // staged pixels as floats: converted once per pixel,
-            const bool isRef = k < nL;                   // not once per (pixel, disparity) element
-            const int idx = isRef ? k : k - nL;
+        for (int k = tid; k < nL4 + nT4; k += nthr) {   // staged pixels: norm computed once per pixel,
+            const bool isRef = k < nL4;                  // not once per (pixel, disparity) element
+            const int idx = isRef ? k : k - nL4;
             const int col = (isRef ? seg_lo : tgt_lo) + idx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)col < (unsigned)W) v = bgr_unpack((isRef ? A.ref : A.tgt)[(size_t)r * W + col], 1.f);
+            GswPix v = gsw_pix(0u, 0.f);
+            if ((unsigned)col < (unsigned)W) v = gsw_pix((isRef ? A.ref : A.tgt)[(size_t)r * W + col], 1.f);
             (isRef ? refS : tgtS)[idx] = v;
         }
         __syncthreads();
 
         // ---- support weights of this image row for the tile's reference pixels, per output row:
-        //      image row r is window row i = r - y + pad of output row y
+        //      image row r is window row i = r - y + pad of output row y.  A thread keeps one reference
+        //      column c (its centre pixel is fetched once) and walks the tap columns j.
         bool use[TY];
 #pragma unroll
-        for (int t = 0; t < TY; ++t) {
-            const int y = y0 + t, i = r - y + p;
-            use[t] = t < ny && (unsigned)i < (unsigned)win;
-            if (!use[t]) continue;
-            float *const wT = wS + t * win * Tx;
-            for (int k = tid; k < Tx * win; k += nthr) {
-                const int j = k / Tx, c = k - j * Tx;
-                const int x = x0 + c, col = x - p + j;
-                float w = 0.f;
-                if (x < W && (unsigned)col < (unsigned)W) {
-                    const bool centre = (i == p) && (j == p);
-                    bool reached = A.iterations > 0;
-                    if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
-                    if (centre) w = 1.0f;                                                   // exp(-0/gamma)
-                    else if (reached) {
-                        const float4 cpx = bgr_unpack(A.ref[(size_t)y * W + x], 1.f);
-                        w = A.tab[(int)bgr_dist2f(refS[c + j], cpx)];
+        for (int t = 0; t < TY; ++t) use[t] = t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win;
+        {
+            const int lanesX = min(Tx, nthr), qw = nthr / lanesX;
+            const int c0 = tid % lanesX, jq = tid / lanesX;
+            if (jq < qw) {
+                for (int c = c0; c < Tx; c += lanesX) {
+                    const int x = x0 + c;
+#pragma unroll
+                    for (int t = 0; t < TY; ++t) {
+                        if (!use[t]) continue;
+                        const int y = y0 + t, i = r - y + p;
+                        float *const wT = wS + t * win * Tx + c;
+                        bool reached = A.iterations > 0 && x < W;
+                        if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
+                        const GswPix cpx = gsw_pix(x < W ? A.ref[(size_t)y * W + x] : 0u, 1.f);
+                        for (int j = jq; j < win; j += qw) {
+                            const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
+                            float w = 0.f;
+                            if (x < W && px.inside != 0.f) {
+                                if (i == p && j == p) w = 1.0f;                               // exp(-0/gamma)
+                                else if (reached) w = A.tab[gsw_dist2(px, cpx)];
+                            }
+                            wT[j * Tx] = w;
+                        }
                     }
                 }
-                wT[k] = w;
             }
         }
         // ---- e[ul][d] = min(fMax, ||ref(r,u) - tgt(r,u -/+ d)||), 0 when the target column is outside.
-        //      Task = (column ul, disparity dd) with dd fastest across the lanes of a wave: the e writes of
-        //      a wave then fall into consecutive floats (the column-fastest order put 64 lanes on 4 banks),
-        //      the reference pixel is a broadcast read and the target pixels are consecutive 16-byte reads.
-        //      Task index advanced without divisions; four independent elements per iteration (LDS reads
-        //      first, then the sub/fma/sqrt chains).
+        //      A task is four adjacent columns ul = 4m .. 4m+3 at one disparity dd: they share the swizzle
+        //      key, so one address computation serves four independent sub/dot/sqrt chains.  Each thread
+        //      keeps its dd and walks m with a constant stride; dd is fastest across the lanes of a wave:
+        //      the e writes of a wave fall into consecutive floats, the reference pixels are broadcast
+        //      reads and the target pixels consecutive 16-byte reads.  (nL is padded to a multiple of 4;
+        //      the padding columns hold outside-the-image pixels and are never read by the taps.)
         {
-            const int e_q = nthr / Dc, e_r = nthr - e_q * Dc;
-            int ul = tid / Dc, dd = tid - ul * Dc;
-            while (ul < nL) {
-                int uls[4], dds[4];
-                float4 rp[4], tp[4];
-                float ev[4];
+            const int lanesD = min(Dc, nthr), q = nthr / lanesD;
+            const int dd0 = tid % lanesD, mq = tid / lanesD;
+            if (mq < q) {
+                for (int dd = dd0; dd < Dc; dd += lanesD) {
+                    const int tofs = right ? dd : (Dc - 1) - dd;
+                    const int eofs = dd & 7, slot = dd >> 3;
+                    for (int m = mq; 4 * m < nL; m += q) {
+                        const GswPix *const rp = refS + 4 * m, *const tp = tgtS + 4 * m + tofs;
+                        float *const ep = eT + gsw_e_offset(4 * m, slot, Ses, emask) + eofs;
+                        GswPix rv[4], tv[4];
+                        float ev[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    uls[u] = min(ul, nL - 1); dds[u] = dd;      // tasks past the end repeat the last column
-                    dd += e_r; ul += e_q;
-                    if (dd >= Dc) { dd -= Dc; ++ul; }
+                        for (int u = 0; u < 4; ++u) { rv[u] = rp[u]; tv[u] = tp[u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ev[u] = (float)gsw_dist2(rv[u], tv[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ev[u] = fminf(A.fMax, gsw_sqrt_int(ev[u])) * tv[u].inside;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ep[u << Ses] = ev[u];
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int tix = right ? uls[u] + dds[u] : uls[u] + (Dc - 1) - dds[u];
-                    rp[u] = refS[uls[u]];
-                    tp[u] = tgtS[tix];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) ev[u] = bgr_dist2f(rp[u], tp[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) ev[u] = fminf(A.fMax, gsw_sqrt_int(ev[u]));
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    eT[gsw_e_offset(uls[u], dds[u] >> 3, Se, emask) + (dds[u] & 7)] = tp[u].w == 0.f ? 0.f : ev[u];
             }
         }
         __syncthreads();
 
         if (active) {
             if constexpr (TY == 1) {
-                gsw_row_taps<1, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
+                gsw_row_taps<1, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
             } else {
                 static_assert(TY == 2, "strips of 1 or 2 output rows");
-                if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
-                else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
-                else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wS, eT, win, Tx, xg, dg, Se, emask);
+                if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
+                else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
+                else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
             }
         }
     }

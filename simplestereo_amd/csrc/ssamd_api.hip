@@ -396,13 +396,16 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
     int P = 1;
     while (8 * P < g.Dc) P <<= 1;
     g.Se = 8 * P;                                  // floats per e row (slots of 8 disparities)
+    g.Ses = 3;
+    while ((1 << g.Ses) < g.Se) ++g.Ses;
     g.emask = std::min(P, 32) - 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
     g.off_w = take((size_t)Ty * win * g.Tx * 4);
-    g.off_e = take((size_t)g.nL * g.Se * 4);
-    g.off_ref = take((size_t)g.nL * 16);
-    g.off_tgt = take((size_t)g.nT * 16);
+    const int nL4 = round_up(g.nL, 4);                 // the e tasks cover 4 columns
+    g.off_e = take((size_t)nL4 * g.Se * 4);
+    g.off_ref = take((size_t)nL4 * 16);
+    g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16);
     g.off_best = take((size_t)Ty * g.Tx * 8);
     g.lds_bytes = (int)off;
     return off <= limit;
