@@ -105,51 +105,53 @@ __device__ __forceinline__ void gsw_taps(float (&cost)[GSW_RX][RD], const float4
     }
 }
 
-// RD consecutive disparities of e row ul; dg = index of the thread's disparity group (RD = 8: one
-// 32-byte slot, RD = 4: half a slot)
+// RD consecutive disparities of an e row, from its (swizzled) address
 template <int RD>
-__device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e, int ul, int dg, int Ses, int emask)
+__device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e)
 {
     static_assert(RD == 4 || RD == 8, "thread tiles of 4 or 8 disparities");
+    const float4 a = *reinterpret_cast<const float4 *>(e);
+    row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
     if constexpr (RD == 8) {
-        const int off = gsw_e_offset(ul, dg, Ses, emask);
-        const float4 a = *reinterpret_cast<const float4 *>(e + off);
-        const float4 b = *reinterpret_cast<const float4 *>(e + off + 4);
-        row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
+        const float4 b = *reinterpret_cast<const float4 *>(e + 4);
         row[4] = b.x; row[5] = b.y; row[6] = b.z; row[7] = b.w;
-    } else {
-        const float4 a = *reinterpret_cast<const float4 *>(e + gsw_e_offset(ul, dg >> 1, Ses, emask) + 4 * (dg & 1));
-        row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
     }
 }
 
 // All tap columns of the current image row for output rows [T0, T1) of the strip.  The e rows slide
 // through four register rows (one new row per tap column) and are shared by the output rows.
+// The thread's columns start at ul0 = 4 xg, so e row ul0 + n has swizzle key xg + n/4: the key
+// changes once per four tap columns and the address of a row is pointer + n * pitch + key term.
 template <int TY, int RD, int T0, int T1>
 __device__ __forceinline__ void gsw_row_taps(float (&cost)[TY][GSW_RX][RD], const float *wS, const float *eT, int win,
                                              int Tx, int xg, int dg, int Ses, int emask)
 {
     const float *wp = wS + GSW_RX * xg;
-    const int ul0 = GSW_RX * xg, wstride = win * Tx;
-#define SSAMD_GROW(dst, n) gsw_load_row<RD>(dst, eT, ul0 + (n), dg, Ses, emask)
-#define SSAMD_GSTEP(j, ra, rb, rc, rd)                                                                        \
+    const int wstride = win * Tx, pitch = 1 << Ses;
+    const int slot = RD == 8 ? dg : dg >> 1, half = RD == 8 ? 0 : 4 * (dg & 1);    // dg-th group of RD disparities
+    auto key = [&](int k) { return ((slot ^ ((xg + k) & emask)) << 3) + half; };
+    const float *er = eT + ((GSW_RX * xg) << Ses);       // row ul0 + j0
+    int kA = key(0), kB = key(1);
+#define SSAMD_GSTEP(j, ra, rb, rc, rd, K)                                                                     \
     if ((j) < win) {                                                                                          \
-        SSAMD_GROW(rd, (j) + 3);                                                                              \
+        gsw_load_row<RD>(rd, er + (3 + (j) - j0) * pitch + K);                                                \
         _Pragma("unroll") for (int t = T0; t < T1; ++t)                                                       \
             gsw_taps<RD>(cost[t], *reinterpret_cast<const float4 *>(wp + t * wstride + (j) * Tx), ra, rb, rc, rd); \
     }
     float e0[RD], e1[RD], e2[RD], e3[RD];
-    SSAMD_GROW(e0, 0);
-    SSAMD_GROW(e1, 1);
-    SSAMD_GROW(e2, 2);
+    gsw_load_row<RD>(e0, er + kA);
+    gsw_load_row<RD>(e1, er + pitch + kA);
+    gsw_load_row<RD>(e2, er + 2 * pitch + kA);
     for (int j0 = 0; j0 < win; j0 += 4) {
-        SSAMD_GSTEP(j0, e0, e1, e2, e3)
-        SSAMD_GSTEP(j0 + 1, e1, e2, e3, e0)
-        SSAMD_GSTEP(j0 + 2, e2, e3, e0, e1)
-        SSAMD_GSTEP(j0 + 3, e3, e0, e1, e2)
+        SSAMD_GSTEP(j0, e0, e1, e2, e3, kA)              // rows ul0 + j0 + 3 | + 4 .. + 6: keys j0/4 | j0/4 + 1
+        SSAMD_GSTEP(j0 + 1, e1, e2, e3, e0, kB)
+        SSAMD_GSTEP(j0 + 2, e2, e3, e0, e1, kB)
+        SSAMD_GSTEP(j0 + 3, e3, e0, e1, e2, kB)
+        er += 4 * pitch;
+        kA = kB;
+        kB = key(j0 / 4 + 2);
     }
 #undef SSAMD_GSTEP
-#undef SSAMD_GROW
 }
 
 template <int TY, int RD>
@@ -226,14 +228,21 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
                         bool reached = A.iterations > 0 && x < W;
                         if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
                         const GswPix cpx = gsw_pix(x < W ? A.ref[(size_t)y * W + x] : 0u, 1.f);
-                        for (int j = jq; j < win; j += qw) {
-                            const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
-                            float w = 0.f;
-                            if (x < W && px.inside != 0.f) {
-                                if (i == p && j == p) w = 1.0f;                               // exp(-0/gamma)
-                                else if (reached) w = A.tab[gsw_dist2(px, cpx)];
+                        // two tap columns per batch, branch-free: their table gathers are in flight together
+                        for (int jb = jq; jb < win; jb += 2 * qw) {
+                            float w[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int j = min(jb + u * qw, win - 1);
+                                const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
+                                const bool centre = i == p && j == p;
+                                const bool gather = reached && !centre && px.inside != 0.f;
+                                const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
+                                w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
                             }
-                            wT[j * Tx] = w;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                if (jb + u * qw < win) wT[(jb + u * qw) * Tx] = w[u];
                         }
                     }
                 }
