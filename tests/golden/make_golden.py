@@ -105,6 +105,18 @@ def main():
         "G6h": ("synth_480x640", G(winSize=11, maxDisparity=64, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
         "G8a": ("tsukuba_top", G(winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
         "G8b": ("tsukuba_top", A(winSize=21, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True)),
+        # parameter corners: 1x1 window, extreme gammas, centre-only GSW weights (iterations=0), tiny / zero fMax,
+        # negative GSW gamma (growing weights), empty candidate range, class defaults on a real image
+        "G9a": ("crop", A(winSize=1, maxDisparity=8, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True)),
+        "G9b": ("crop", A(winSize=9, maxDisparity=12, minDisparity=0, gammaC=0.7, gammaP=3.0, consistent=False)),
+        "G9c": ("crop", A(winSize=9, maxDisparity=12, minDisparity=0, gammaC=60, gammaP=200, consistent=True)),
+        "G9d": ("crop", G(winSize=7, maxDisparity=8, minDisparity=0, gamma=10, fMax=120, iterations=0, bins=20)),
+        "G9e": ("crop", G(winSize=7, maxDisparity=8, minDisparity=0, gamma=1, fMax=5.5, iterations=3, bins=20)),
+        "G9f": ("crop", G(winSize=5, maxDisparity=9, minDisparity=2, gamma=-7, fMax=120, iterations=3, bins=20)),
+        "G9g": ("crop", A(winSize=5, maxDisparity=3, minDisparity=5, gammaC=5, gammaP=17.5, consistent=False)),
+        "G9h": ("tsukuba_top", A(winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False)),
+        "G9i": ("crop", G(winSize=5, maxDisparity=6, minDisparity=0, gamma=10, fMax=0, iterations=3, bins=20)),
+        "G9j": ("crop", G(winSize=1, maxDisparity=6, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
     }
 
     maps, meta = {}, {}
