@@ -26,9 +26,11 @@ twice, ``_passive.cpp:309``), non-contiguous inputs are made contiguous (the
 reference reads them as if contiguous), negative ``minDisparity`` is rejected
 (out-of-bounds reads in the reference).
 
-Extension (not in the reference): ``compute`` also accepts two CUDA/HIP
+Extensions (not in the reference): ``compute`` also accepts two CUDA/HIP
 ``torch.uint8`` tensors ``[H,W,3]`` already resident in HBM and then returns a
-``torch.int16`` tensor on the same device without any host round trip.
+``torch.int16`` tensor on the same device without any host round trip; and both
+classes take one extra trailing keyword, ``device`` (default ``None`` = the
+process's current HIP device), the GPU index that host-array calls run on.
 """
 import ctypes
 import operator
@@ -88,6 +90,16 @@ def _check_pair_tensors(t1, t2):
     return t1.contiguous(), t2.contiguous()
 
 
+def _device_index(device):
+    """None -> -1 (current device of the calling thread); otherwise a non-negative GPU index."""
+    if device is None:
+        return -1
+    i = _c_int(device)
+    if i < 0:
+        raise ValueError("device must be None or a non-negative GPU index")
+    return i
+
+
 def _raise_native(e):
     if e.code == -1:
         raise ValueError(e.message) from None
@@ -111,6 +123,8 @@ class StereoASW():
         Scale of the colour term exp(-dLab / gammaC) of the support weights (default 5).
     gammaP : float
         Scale of the spatial term exp(-dist / gammaP) of the support weights (default 17.5).
+    device : int or None
+        Extension: GPU index for host-array calls (default None: the current HIP device).
     consistent : bool
         Also match with the right image as reference, invalidate left pixels whose match does
         not agree, and fill each invalid run with the smaller of its two valid neighbours
@@ -118,9 +132,11 @@ class StereoASW():
         because the aggregated cost is symmetric in the (left pixel, right pixel) pair.
     """
 
-    def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False):
+    def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
+                 device=None):
         if not (winSize > 0 and winSize % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
+        self.device = device
         self.winSize = winSize
         self.maxDisparity = maxDisparity
         self.minDisparity = minDisparity
@@ -147,6 +163,7 @@ class StereoASW():
         if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
             raise ValueError("Invalid input format!")
         win, maxd, mind, gc, gp, cons = self._params()
+        dev = _device_index(getattr(self, "device", None))
         a, b = _check_pair(img1, img2)
         if not (win > 0 and win % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
@@ -154,7 +171,7 @@ class StereoASW():
         out = np.empty((H, W), np.int16)
         try:
             _native.check(lib.ssamd_asw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
-                                        out.ctypes.data, -1))
+                                        out.ctypes.data, dev))
         except _native.NativeError as e:
             _raise_native(e)
         return out
@@ -205,11 +222,15 @@ class StereoGSW():
         weights, 0 keeps only the window centre (default 3).
     bins : int
         Accepted for signature compatibility; the reference never reads it (default 20).
+    device : int or None
+        Extension: GPU index for host-array calls (default None: the current HIP device).
     """
 
-    def __init__(self, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20):
+    def __init__(self, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20,
+                 device=None):
         if not (winSize > 0 and winSize % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
+        self.device = device
         self.winSize = winSize
         self.gamma = gamma
         self.maxDisparity = maxDisparity
@@ -230,6 +251,7 @@ class StereoGSW():
         if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
             raise ValueError("Invalid input format!")
         win, maxd, mind, gamma, fmax, it, bins = self._params()
+        dev = _device_index(getattr(self, "device", None))
         a, b = _check_pair(img1, img2)
         if not (win > 0 and win % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
@@ -237,7 +259,7 @@ class StereoGSW():
         out = np.empty((H, W), np.int16)
         try:
             _native.check(lib.ssamd_gsw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gamma, fmax, it, bins,
-                                        out.ctypes.data, -1))
+                                        out.ctypes.data, dev))
         except _native.NativeError as e:
             _raise_native(e)
         return out

@@ -20,15 +20,19 @@ def ss():
 
 
 def test_signatures_match_reference(ss):
-    """passive.py:59 and passive.py:133-134 of the reference"""
+    """passive.py:59 and passive.py:133-134 of the reference; our only addition is a trailing
+    `device=None` keyword, so every positional / keyword call of the reference binds identically"""
     sig = inspect.signature(ss.passive.StereoASW.__init__)
     assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
         ("winSize", 35), ("maxDisparity", 16), ("minDisparity", 0), ("gammaC", 5), ("gammaP", 17.5),
-        ("consistent", False)]
+        ("consistent", False), ("device", None)]
     sig = inspect.signature(ss.passive.StereoGSW.__init__)
     assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
         ("winSize", 11), ("maxDisparity", 16), ("minDisparity", 0), ("gamma", 10), ("fMax", 120),
-        ("iterations", 3), ("bins", 20)]
+        ("iterations", 3), ("bins", 20), ("device", None)]
+    with pytest.raises(ValueError):
+        ss.passive._device_index(-2)
+    assert ss.passive._device_index(None) == -1 and ss.passive._device_index(3) == 3
     m = ss.passive.StereoASW(winSize=7, maxDisparity=3)
     assert (m.winSize, m.maxDisparity, m.minDisparity, m.gammaC, m.gammaP, m.consistent) == (7, 3, 0, 5, 17.5, False)
     g = ss.passive.StereoGSW()

@@ -104,3 +104,18 @@ def test_calls_on_different_streams_do_not_race_on_scratch(ss, golden_inputs):
     torch.cuda.synchronize()
     for o1, o2 in outs:
         assert np.array_equal(o1.cpu().numpy(), want1) and np.array_equal(o2.cpu().numpy(), want2)
+
+
+def test_device_keyword_selects_gpu_or_fails_loudly(golden_inputs):
+    """extension keyword `device`: index 0 == default device here; a missing GPU is an error, never a fallback"""
+    import simplestereo_amd as ss
+    from simplestereo_amd import _native
+    a, b = golden_inputs("crop")
+    want = ss.passive.StereoASW(winSize=7, maxDisparity=6).compute(a, b)
+    assert np.array_equal(ss.passive.StereoASW(winSize=7, maxDisparity=6, device=0).compute(a, b), want)
+    g = ss.passive.StereoGSW(winSize=5, maxDisparity=6)
+    want_g = g.compute(a, b)
+    g.device = 0
+    assert np.array_equal(g.compute(a, b), want_g)
+    with pytest.raises(ValueError, match="out of range"):
+        ss.passive.StereoASW(winSize=7, maxDisparity=6, device=_native.lib().ssamd_device_count() + 5).compute(a, b)
