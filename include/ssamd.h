@@ -86,6 +86,22 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream);
 
+/* ---- "alternate pixel" ASW -------------------------------------
+ * The faster variant the reference only sketches in a docstring todo (passive.py:43-46: "compute
+ * disparity map on every other pixel with the traditional algorithm, then fill the remaining
+ * pixels using left-right disparity boundaries"); opt-in, never the default.  Even image rows are
+ * matched exactly; a pixel of an odd row searches only the disparities between the results of the
+ * pixels above and below it (copied when they agree), with the exact ASW cost.  Whole images only,
+ * no consistency pass.  Same buffers and error codes as ssamd_asw / ssamd_asw_device. */
+int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                        int winSize, int maxDisparity, int minDisparity,
+                        double gammaC, double gammaP,
+                        int16_t *disparity, int device);
+int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                               int winSize, int maxDisparity, int minDisparity,
+                               double gammaC, double gammaP,
+                               int16_t *d_disparity, void *stream);
+
 /* ---- the steps either side of the matchers, on device --------- */
 
 /* RectifiedStereoRig.rectifyImages (reference _rigs.py:543-567 = cv2.remap with constant
@@ -128,7 +144,8 @@ int ssamd_debug_gsw_sqrt(int n, float *out);
 #define SSAMD_K_GSW_FIN 4    /* GSW LR check / occlusion fill                    */
 #define SSAMD_K_REMAP 5      /* rectification remap (bilinear)                    */
 #define SSAMD_K_REPROJECT 6  /* disparity -> 3-D points                           */
-#define SSAMD_K_COUNT 7
+#define SSAMD_K_ASW_ALT 7    /* alternate-rows mode: bounded search on the odd rows */
+#define SSAMD_K_COUNT 8
 int ssamd_profile_enable(int on);
 int ssamd_profile_reset(void);
 int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);

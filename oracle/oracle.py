@@ -82,6 +82,41 @@ def asw(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gamma
     return (out, costs) if return_costs else out
 
 
+def asw_alternate(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, exact_rows=None):
+    """CPU restatement of the alternate-rows ASW mode (simplestereo_amd/csrc/asw_alt_kernels.hip.h).
+
+    The reference only sketches the idea (docstring todo, reference passive.py:43-46) -- there is no
+    reference output to pin this against ("parity unpinned" for this mode).  The restatement uses the
+    reference-exact pieces: even rows = the exact map of ``asw`` (restated _passive.cpp:34-100), odd
+    rows = argmin of the reference's fp64 costs over the disparities between the results above and
+    below (first minimum wins, as in _passive.cpp:90-93).  ``exact_rows``: optional [H,W] map whose even
+    rows replace the oracle's own (to test the fill stage in isolation from fp32-vs-fp64 argmin ties
+    on the exact rows).  Returns (map, number of evaluated pixels)."""
+    exact, costs = asw(img1, img2, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent=False,
+                       hoist=True, return_costs=True) if maxDisparity >= minDisparity else (asw(
+                           img1, img2, winSize, maxDisparity, minDisparity, gammaC, gammaP), None)
+    out = np.array(exact if exact_rows is None else exact_rows, dtype=np.int32)
+    H, W = out.shape
+    evaluated = 0
+    for y in range(1, H, 2):
+        up = out[y - 1]
+        down = out[y + 1] if y + 1 < H else up
+        for x in range(W):
+            dmaxv = min(maxDisparity, x)
+            if minDisparity > dmaxv:                 # empty candidate loop: the exact mode writes x
+                out[y, x] = x
+                continue
+            lo = min(max(min(up[x], down[x]), minDisparity), dmaxv)
+            hi = min(max(max(up[x], down[x]), minDisparity), dmaxv)
+            if lo == hi:
+                out[y, x] = lo
+                continue
+            c = costs[y, x, lo - minDisparity:hi - minDisparity + 1]
+            out[y, x] = lo + int(np.argmin(c))       # np.argmin: first minimum = smallest disparity
+            evaluated += 1
+    return out.astype(np.int16), evaluated
+
+
 def gsw(img1, img2, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120,
         iterations=3, bins=20, closed=False, nthreads=0):
     """C restatement of ``_passive.computeGSW`` (reference _passive.cpp:703-774)."""

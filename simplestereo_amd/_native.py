@@ -9,7 +9,7 @@ import os
 
 from .build import LIB_PATH
 
-K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_ASW_ALT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _lib = None
 _u8p = ctypes.c_void_p
@@ -48,6 +48,10 @@ def lib():
     L.ssamd_asw_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_gsw_device.restype = I
     L.ssamd_gsw_device.argtypes = [P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]
+    L.ssamd_asw_alternate.restype = I
+    L.ssamd_asw_alternate.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
+    L.ssamd_asw_alternate_device.restype = I
+    L.ssamd_asw_alternate_device.argtypes = [P, P, I, I, I, I, I, D, D, P, P]
     L.ssamd_asw_costs.restype = I
     L.ssamd_asw_costs.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
     L.ssamd_bgr2lab.restype = I

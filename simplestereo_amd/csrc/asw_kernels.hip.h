@@ -58,6 +58,7 @@ struct AswArgs {
     u64 *keyR;                   // [rows][W] right-referenced WTA keys (cost, xl) or nullptr
     float *costs;                // optional [rows][W][nD] raw cost dump
     int H, W, win, pad, minD, maxD, row0, rows;
+    int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)
     float kC;                    // -log2(e)/gammaC
     AswGeom g;
 };
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     int bx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
     const int x0 = bx * Tx;
-    const int y = A.row0 + blockIdx.y;
+    const int y = A.row0 + blockIdx.y * A.ystep;
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
     // no (x,d) pair of this tile has x-d >= 0 (left image border): nothing to do

@@ -15,6 +15,7 @@
 
 #include "../../include/ssamd.h"
 #include "asw_kernels.hip.h"
+#include "asw_alt_kernels.hip.h"
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
 #include "rig_kernels.hip.h"
@@ -94,7 +95,7 @@ struct Ctx {
     int dev = -1;
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
-    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, prox, costs, gswTab, lab;
+    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, prox, costs, gswTab, lab, altq;
     // cached small tables
     int prox_win = -1; double prox_gammaP = -1;
     int gsw_gamma = -1; float gsw_fmax = -1.f;
@@ -338,11 +339,13 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
 
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
-                    float *d_costs, hipStream_t s)
+                    float *d_costs, hipStream_t s, bool alternate = false)
 {
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
+    if (alternate && (consistent || d_costs || row0 != 0 || rows != H))
+        return fail(SSAMD_EINVAL, "the alternate-rows mode takes the whole image and neither consistent nor a cost dump");
     if (rows == 0) return SSAMD_OK;
     ScratchOrder order(c, s);
     const int p = win / 2, nD = maxD - minD + 1;
@@ -362,14 +365,16 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
 
         AswArgs a;
-        if ((rc = asw_choose_geometry(a.g, W, rows, win, nD))) return rc;
+        if ((rc = asw_choose_geometry(a.g, W, alternate ? (rows + 1) / 2 : rows, win, nD))) return rc;
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
         a.prox = (const float *)c.prox.ptr;
         a.keyL = (u64 *)c.keyL.ptr; a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
         a.costs = d_costs;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
-        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, rows, a.g.nchunks), block(a.g.threads);
+        a.ystep = alternate ? 2 : 1;
+        const int grows = alternate ? (rows + 1) / 2 : rows;          // workgroup rows: every row, or the even ones
+        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, grows, a.g.nchunks), block(a.g.threads);
         const bool chunked = a.g.JC < win;
         auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
                             : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
@@ -380,7 +385,32 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             HIP_TRY(hipGetLastError());
         }
     }
-    return launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s);
+    if ((rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s))) return rc;
+    if (alternate && rows > 1) {
+        // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
+        // empty disparity range the decode already wrote x everywhere and the fill reproduces it.
+        AswAltArgs f;
+        const size_t nodd = (size_t)(rows / 2) * W;
+        if ((double)nodd * ((nD + 7) / 8 + 1) >= 4.0e9)
+            return fail(SSAMD_ELIMIT, "alternate-rows mode: image x disparity range too large for the 32-bit job counter");
+        f.cap = (unsigned int)std::min<size_t>(std::max<size_t>(nodd, 1 << 16), 1u << 28);   // jobs of 8 candidates
+        if (const char *env = getenv("SSAMD_ALT_QUEUE_CAP"))        // test hook: a tiny queue forces the in-place path
+            f.cap = (unsigned int)std::max(1, atoi(env));
+        if ((rc = c.altq.reserve((size_t)f.cap * 8 + 16))) return rc;
+        f.ctr = (unsigned int *)c.altq.ptr; f.queue = (u64 *)((char *)c.altq.ptr + 16);
+        HIP_TRY(hipMemsetAsync(f.ctr, 0, 16, s));
+        f.recL = (const PixRec *)c.recL.ptr; f.recR = (const PixRec *)c.recR.ptr; f.prox = (const float *)c.prox.ptr;
+        f.disp = d_disp; f.key = (u64 *)c.keyL.ptr;
+        f.H = H; f.W = W; f.win = win; f.pad = p; f.minD = minD; f.maxD = maxD;
+        f.kC = (float)(-1.4426950408889634 / gammaC);
+        const dim3 pix_grid((W + 255) / 256, rows / 2);
+        Timed t(c, s, SSAMD_K_ASW_ALT);
+        hipLaunchKernelGGL(asw_alt_scan_kernel, pix_grid, dim3(256), 0, s, f);
+        hipLaunchKernelGGL(asw_alt_jobs_kernel, dim3(256 * 8), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(asw_alt_decode_kernel, pix_grid, dim3(256), 0, s, f);
+        HIP_TRY(hipGetLastError());
+    }
+    return SSAMD_OK;
 }
 
 
@@ -549,7 +579,8 @@ int ssamd_device_count(void)
 const char *ssamd_kernel_name(int slot)
 {
     static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel", "asw_aggregate_kernel", "asw finalize (wta_decode / lr_check_fill)",
-                                               "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel"};
+                                               "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
+                                               "asw_alt_fill_kernel"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
 }
 
@@ -597,7 +628,7 @@ int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
 }
 
 static int asw_host(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, double gammaC,
-                    double gammaP, int consistent, int16_t *disparity, float *costs, int device)
+                    double gammaP, int consistent, int16_t *disparity, float *costs, int device, bool alternate = false)
 {
     if (!img1 || !img2 || (!disparity && !costs)) return fail(SSAMD_EINVAL, "NULL buffer");
     Ctx *c;
@@ -613,7 +644,8 @@ static int asw_host(const uint8_t *img1, const uint8_t *img2, int H, int W, int 
     HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, nb, hipMemcpyHostToDevice, s));
     if (costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
     rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, H, W, 0, H, win, maxD, minD,
-                         gammaC, gammaP, consistent, (int16_t *)c->disp.ptr, costs ? (float *)c->costs.ptr : nullptr, s);
+                         gammaC, gammaP, consistent, (int16_t *)c->disp.ptr, costs ? (float *)c->costs.ptr : nullptr, s,
+                         alternate);
     if (rc) return rc;
     if (disparity) HIP_TRY(hipMemcpyAsync(disparity, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
     if (costs) HIP_TRY(hipMemcpyAsync(costs, c->costs.ptr, ncost * 4, hipMemcpyDeviceToHost, s));
@@ -628,6 +660,28 @@ int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width, i
     if (!disparity) return fail(SSAMD_EINVAL, "NULL buffer");
     return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
                     disparity, nullptr, device);
+}
+
+int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                        int minDisparity, double gammaC, double gammaP, int16_t *disparity, int device)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, disparity, nullptr,
+                    device, true);
+}
+
+int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int winSize,
+                               int maxDisparity, int minDisparity, double gammaC, double gammaP, int16_t *d_disparity,
+                               void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    Ctx *c;
+    int rc = get_ctx(-1, &c);
+    if (rc) return rc;
+    return asw_device_impl(*c, d_img1, d_img2, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC,
+                           gammaP, 0, d_disparity, nullptr, (hipStream_t)stream, true);
 }
 
 int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,

@@ -31,6 +31,9 @@ Extensions (not in the reference): ``compute`` also accepts two CUDA/HIP
 ``torch.int16`` tensor on the same device without any host round trip; and both
 classes take one extra trailing keyword, ``device`` (default ``None`` = the
 process's current HIP device), the GPU index that host-array calls run on.
+``StereoASW`` also takes ``alternate`` (default ``False``): the faster
+"every other pixel" variant that the reference's docstring sketches as a todo
+(reference ``passive.py:43-46``) and never implemented.
 """
 import ctypes
 import operator
@@ -125,6 +128,12 @@ class StereoASW():
         Scale of the spatial term exp(-dist / gammaP) of the support weights (default 17.5).
     device : int or None
         Extension: GPU index for host-array calls (default None: the current HIP device).
+    alternate : bool
+        Extension, the todo of the reference's docstring (``passive.py:43-46``): match every other image
+        row exactly and let each pixel of the rows in between search only the disparities between the
+        results above and below it (copied when they agree).  About twice as fast; not the reference's
+        output (about 2-3 % of the pixels differ on Tsukuba, bad-1.0 against the ground truth does not
+        get worse).  Whole images only; cannot be combined with ``consistent`` (default False).
     consistent : bool
         Also match with the right image as reference, invalidate left pixels whose match does
         not agree, and fill each invalid run with the smaller of its two valid neighbours
@@ -133,10 +142,11 @@ class StereoASW():
     """
 
     def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
-                 device=None):
+                 device=None, alternate=False):
         if not (winSize > 0 and winSize % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
         self.device = device
+        self.alternate = alternate
         self.winSize = winSize
         self.maxDisparity = maxDisparity
         self.minDisparity = minDisparity
@@ -148,6 +158,15 @@ class StereoASW():
         win, maxd, mind = _c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity)
         gc, gp = _c_double(self.gammaC), _c_double(self.gammaP)
         return win, maxd, mind, gc, gp, 1 if self.consistent else 0
+
+    def _alternate(self, cons, whole_image=True):
+        if not getattr(self, "alternate", False):
+            return False
+        if cons:
+            raise ValueError("alternate=True cannot be combined with consistent=True")
+        if not whole_image:
+            raise ValueError("alternate=True needs the whole image (no row strips)")
+        return True
 
     def compute(self, img1, img2):
         """
@@ -170,6 +189,10 @@ class StereoASW():
         H, W = a.shape[:2]
         out = np.empty((H, W), np.int16)
         try:
+            if self._alternate(cons):
+                _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp,
+                                                      out.ctypes.data, dev))
+                return out
             _native.check(lib.ssamd_asw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
                                         out.ctypes.data, dev))
         except _native.NativeError as e:
@@ -187,10 +210,15 @@ class StereoASW():
             raise ValueError("winSize must be a positive odd number!")
         H, W = int(a.shape[0]), int(a.shape[1])
         rows = H - out_row0 if out_rows is None else int(out_rows)
+        alt = self._alternate(cons, whole_image=(out_row0 == 0 and rows == H))
         out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
         with torch.cuda.device(a.device):
             stream = torch.cuda.current_stream(a.device).cuda_stream
             try:
+                if alt:
+                    _native.check(lib.ssamd_asw_alternate_device(a.data_ptr(), b.data_ptr(), H, W, win, maxd, mind,
+                                                                 gc, gp, out.data_ptr(), ctypes.c_void_p(stream)))
+                    return out
                 _native.check(lib.ssamd_asw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
                                                    maxd, mind, gc, gp, cons, out.data_ptr(),
                                                    ctypes.c_void_p(stream)))

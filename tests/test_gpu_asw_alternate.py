@@ -1,0 +1,111 @@
+"""GPU tier: the opt-in "alternate pixel" ASW mode (a docstring todo in the reference,
+passive.py:43-46, without code -- so there is no reference output and this mode is checked against our
+own CPU restatement built from the reference-exact pieces, oracle.asw_alternate, and by its properties)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WITHIN1, EXACT = 0.995, 0.99
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    import simplestereo_amd
+    return simplestereo_amd
+
+
+def _pairs(golden_inputs):
+    a, b = golden_inputs("tsukuba")
+    yield "tsukuba_rows", np.ascontiguousarray(a[60:131]), np.ascontiguousarray(b[60:131]), dict(winSize=15, maxDisparity=16)
+    yield "tsukuba_min4", np.ascontiguousarray(a[100:140]), np.ascontiguousarray(b[100:140]), dict(winSize=21, maxDisparity=14, minDisparity=4, gammaC=15.0)
+    a, b = golden_inputs("synth_64x96")
+    yield "synth", a, b, dict(winSize=9, maxDisparity=24, minDisparity=2, gammaC=7.5, gammaP=36.0)
+    a, b = golden_inputs("crop")
+    yield "crop_bigwin", a, b, dict(winSize=35, maxDisparity=8)
+
+
+def test_even_rows_are_the_exact_mode_and_odd_rows_match_the_restatement(ss, golden_inputs):
+    from oracle import oracle
+    for name, a, b, p in _pairs(golden_inputs):
+        exact = ss.passive.StereoASW(**p).compute(a, b)
+        alt = ss.passive.StereoASW(alternate=True, **p).compute(a, b)
+        assert alt.dtype == np.int16 and alt.shape == exact.shape
+        assert np.array_equal(alt[::2], exact[::2]), name            # same kernel, same rows
+        # fill stage in isolation: the restatement starts from the GPU's own exact rows
+        want, evaluated = oracle.asw_alternate(a, b, exact_rows=exact, **p)
+        diff = np.abs(alt[1::2].astype(np.int32) - want[1::2])
+        print(name, "evaluated pixels", evaluated, "odd rows exact %.5f within1 %.5f" % ((diff == 0).mean(), (diff <= 1).mean()))
+        assert evaluated > 0
+        assert (diff <= 1).mean() >= WITHIN1 and (diff == 0).mean() >= EXACT, name
+        # end to end against the fp64 restatement
+        want2, _ = oracle.asw_alternate(a, b, **p)
+        d2 = np.abs(alt.astype(np.int32) - want2)
+        assert (d2 <= 1).mean() >= WITHIN1, name
+        # the bounded search never leaves the interval spanned by its two exact neighbours
+        lo = np.minimum(alt[0:-2:2], alt[2::2]); hi = np.maximum(alt[0:-2:2], alt[2::2])
+        mid = alt[1:-1:2][:lo.shape[0]]
+        x = np.arange(alt.shape[1])[None, :]
+        valid = x >= p.get("minDisparity", 0)
+        lo_c = np.clip(lo, p.get("minDisparity", 0), np.minimum(p["maxDisparity"], x))
+        hi_c = np.clip(hi, p.get("minDisparity", 0), np.minimum(p["maxDisparity"], x))
+        assert np.all(((mid >= lo_c) & (mid <= hi_c))[np.broadcast_to(valid, mid.shape)]), name
+
+
+def test_alternate_device_tensors_edges_and_errors(ss, golden_inputs):
+    import torch
+    a, b = golden_inputs("crop")
+    p = dict(winSize=7, maxDisparity=6, minDisparity=1)
+    m = ss.passive.StereoASW(alternate=True, **p)
+    host = m.compute(a, b)
+    dev = m.compute(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert dev.dtype == torch.int16 and np.array_equal(dev.cpu().numpy(), host)
+    exact = ss.passive.StereoASW(**p)
+    for rows in (1, 2, 3):                            # no odd row / last odd row without a row below
+        aa, bb = np.ascontiguousarray(a[:rows]), np.ascontiguousarray(b[:rows])
+        got, ex = m.compute(aa, bb), exact.compute(aa, bb)
+        assert np.array_equal(got[::2], ex[::2])
+        if rows == 2:                                 # row 1 has only the neighbour above: copied
+            lo = np.clip(ex[0], 1, np.minimum(6, np.arange(a.shape[1])))
+            assert np.array_equal(got[1][1:], lo[1:])
+    # empty candidate ranges give x, as in the exact mode (_passive.cpp:54,98)
+    e = ss.passive.StereoASW(winSize=5, maxDisparity=3, minDisparity=7, alternate=True).compute(a, b)
+    assert np.array_equal(e, np.tile(np.arange(a.shape[1], dtype=np.int16), (a.shape[0], 1)))
+    with pytest.raises(ValueError, match="consistent"):
+        ss.passive.StereoASW(alternate=True, consistent=True, **p).compute(a, b)
+    with pytest.raises(ValueError, match="whole image"):
+        m._compute_device(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), out_row0=2, out_rows=6)
+
+
+def test_alternate_quality_on_tsukuba_is_not_worse(ss, golden_inputs):
+    """the reference's note: 'no significant decrease in quality' -- bad-1.0 over the non-occluded pixels"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tsukuba_pair.npz"))
+    a, b, gt, nonocc = z["left"], z["right"], z["groundtruth"], z["nonocc"]
+    g = gt.astype(np.float64) / 16.0 if gt.max() > 64 else gt.astype(np.float64)
+    mask = nonocc > 0
+    bad = {}
+    for alt in (False, True):
+        d = ss.passive.StereoASW(winSize=35, maxDisparity=16, alternate=alt).compute(a, b)
+        bad[alt] = 100.0 * float(np.mean(np.abs(d[mask] - g[mask]) > 1.0))
+    print("Tsukuba win 35 bad-1.0: exact %.3f %%, alternate %.3f %%" % (bad[False], bad[True]))
+    assert bad[True] <= bad[False] + 0.5
+
+
+def test_alternate_full_queue_falls_back_to_in_place_evaluation(ss, golden_inputs):
+    """a job queue that is too small (forced through the SSAMD_ALT_QUEUE_CAP test hook) must not lose work:
+    waves that find it full evaluate their pixels themselves, with the same result"""
+    import os
+    a, b = golden_inputs("tsukuba")
+    a, b = np.ascontiguousarray(a[60:131]), np.ascontiguousarray(b[60:131])
+    m = ss.passive.StereoASW(winSize=15, maxDisparity=16, alternate=True)
+    want = m.compute(a, b)
+    for cap in ("1", "37", "300"):
+        os.environ["SSAMD_ALT_QUEUE_CAP"] = cap
+        try:
+            got = m.compute(a, b)
+        finally:
+            del os.environ["SSAMD_ALT_QUEUE_CAP"]
+        assert np.array_equal(got, want), cap
