@@ -265,6 +265,19 @@ def main():
                      "frac": (VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) / VALU_PEAK_LANEOPS) if k_ms > 0 else None},
             "kernels_ms_per_step": {_native.lib().ssamd_kernel_name(i).decode(): ms[i] / args.steps for i in range(_native.K_COUNT) if launches[i]},
         }
+        if world == 1 and not args.consistent:
+            # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
+            alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
+                                       alternate=True)
+            alt_map = alt.compute(ownL, ownR)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(3):
+                alt_map = alt.compute(ownL, ownR)
+            torch.cuda.synchronize()
+            line["alternate_rows_mode"] = {"ms_per_step": (time.perf_counter() - ta) / 3 * 1e3,
+                                           "percent_pixels_differing_from_exact": 100.0 * float((alt_map != out).float().mean()),
+                                           "note": "opt-in StereoASW(alternate=True); not the reference's output, never `value`"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, args.seed, args.cpu_budget)
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
