@@ -109,3 +109,42 @@ def test_alternate_full_queue_falls_back_to_in_place_evaluation(ss, golden_input
         finally:
             del os.environ["SSAMD_ALT_QUEUE_CAP"]
         assert np.array_equal(got, want), cap
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = [(1, 9, 3, 0, 4, 1), (2, 1, 5, 0, 3, 2), (3, 70, 35, 2, 40, 3), (9, 300, 3, 0, 280, 4)]
+    for k in range(n):
+        out.append((int(rng.integers(2, 34)), int(rng.integers(1, 100)), int(rng.choice([1, 3, 5, 9, 15, 21])),
+                    int(rng.integers(0, 5)), int(rng.integers(0, 60)), 50 + k))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(14, 99))
+def test_alternate_fuzz_vs_restatement(case, ss):
+    """random small shapes: even rows == exact mode; odd rows == the CPU rule applied to the GPU's own exact rows,
+    up to numerical ties of the fp64 costs (1e-6 relative)"""
+    from oracle import oracle
+    from simplestereo_amd.synth import make_pair
+    H, W, win, minD, span, seed = case
+    maxD = minD + span
+    a = make_pair(H, W, 8, seed)[0]
+    a = (100 + (a.astype(np.int32) - 128) // 5).astype(np.uint8)
+    rng = np.random.default_rng(seed)
+    shift = np.repeat(rng.integers(minD, max(minD, min(maxD, W // 2)) + 1, size=(H + 7) // 8), 8)[:H]   # depth steps between rows
+    b = np.stack([np.roll(a[y], -int(shift[y]), axis=0) for y in range(H)]).astype(np.int32) + rng.integers(-2, 3, size=a.shape)
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(np.clip(b, 0, 255).astype(np.uint8))
+    p = dict(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=6.0, gammaP=15.0)
+    exact = ss.passive.StereoASW(**p).compute(a, b)
+    alt = ss.passive.StereoASW(alternate=True, **p).compute(a, b)
+    assert np.array_equal(alt[::2], exact[::2])
+    if H < 2:
+        return
+    want, _ = oracle.asw_alternate(a, b, exact_rows=exact, **p)
+    _, costs = oracle.asw(a, b, return_costs=True, **p) if maxD >= minD else (None, None)
+    bad = 0
+    for y, x in np.argwhere(alt != want):
+        cg, cw = costs[y, x, alt[y, x] - minD], costs[y, x, want[y, x] - minD]
+        if not (np.isfinite(cg) and abs(cg - cw) <= 1e-6 * max(1.0, abs(cw))):
+            bad += 1
+    assert bad == 0, (case, bad)
