@@ -56,6 +56,8 @@ struct AswArgs {
     const float *prox;           // [win*win] proximity weights exp(-|t|/gammaP)
     u64 *keyL;                   // [rows][W] left-referenced WTA keys  (cost, d)
     u64 *keyR;                   // [rows][W] right-referenced WTA keys (cost, xl) or nullptr
+    int16_t *disp;               // non-null: ONE disparity chunk and no right pass -- every pixel is decided by exactly one
+                                 //   workgroup, which writes the disparity itself (no keys, no atomics, no decode kernel)
     float *costs;                // optional [rows][W][nD] raw cost dump
     int H, W, win, pad, minD, maxD, row0, rows;
     int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)
@@ -174,8 +176,14 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     const int y = A.row0 + blockIdx.y * A.ystep;
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
-    // no (x,d) pair of this tile has x-d >= 0 (left image border): nothing to do
-    if (min(x0 + Tx - 1, W - 1) - dlo < 0) return;
+    // no (x,d) pair of this tile has x-d >= 0 (left image border): nothing to aggregate; the empty candidate
+    // loop of the reference leaves dBest = 0, i.e. the output x (_passive.cpp:54,98)
+    if (min(x0 + Tx - 1, W - 1) - dlo < 0) {
+        if (A.disp)
+            for (int k = threadIdx.x; k < Tx && x0 + k < W; k += blockDim.x)
+                A.disp[(size_t)(y - A.row0) * W + x0 + k] = (int16_t)(x0 + k);
+        return;
+    }
 
     const int segL_lo = x0 - p;        // first tap column staged from the left image
     const int xrc_lo = x0 - dhi;       // first right-image window centre of the tile
@@ -427,6 +435,13 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     }
     __syncthreads();
     const size_t orow = (size_t)(y - A.row0) * W;
+    if (A.disp) {
+        for (int k = tid; k < Tx; k += nthr) {
+            const int x = x0 + k;
+            if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
+        }
+        return;
+    }
     for (int k = tid; k < Tx; k += nthr) {
         const int x = x0 + k;
         if (x < W && bestL[k] != KEY_NONE) atomicMin(&A.keyL[orow + x], bestL[k]);

@@ -351,10 +351,19 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     const int p = win / 2, nD = maxD - minD + 1;
     const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
 
-    if ((rc = c.keyL.reserve(nout * 8))) return rc;
-    if (consistent && (rc = c.keyR.reserve(nout * 8))) return rc;
-    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
-    if (consistent) HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+    // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
+    // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
+    AswArgs a;
+    if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, alternate ? (rows + 1) / 2 : rows, win, nD))) return rc;
+    const bool direct = nD >= 1 && a.g.nchunks == 1 && !consistent;
+    if (!direct || alternate) {                 // the alternate mode merges its odd-row jobs through the left keys
+        if ((rc = c.keyL.reserve(nout * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+    }
+    if (consistent) {
+        if ((rc = c.keyR.reserve(nout * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+    }
 
     if (nD >= 1) {
         if ((rc = c.recL.reserve(npix * sizeof(PixRec)))) return rc;
@@ -364,11 +373,10 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
         if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
 
-        AswArgs a;
-        if ((rc = asw_choose_geometry(a.g, W, alternate ? (rows + 1) / 2 : rows, win, nD))) return rc;
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
         a.prox = (const float *)c.prox.ptr;
-        a.keyL = (u64 *)c.keyL.ptr; a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+        a.keyL = direct ? nullptr : (u64 *)c.keyL.ptr; a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+        a.disp = direct ? d_disp : nullptr;
         a.costs = d_costs;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
@@ -385,7 +393,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             HIP_TRY(hipGetLastError());
         }
     }
-    if ((rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s))) return rc;
+    if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s))) return rc;
     if (alternate && rows > 1) {
         // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
         // empty disparity range the decode already wrote x everywhere and the fill reproduces it.
