@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--with-alternate", action="store_true",
+                    help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line.  RCCL (NCCL_DEBUG=VERSION on the GPU boxes) and other
@@ -265,7 +267,7 @@ def main():
                      "frac": (VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) / VALU_PEAK_LANEOPS) if k_ms > 0 else None},
             "kernels_ms_per_step": {_native.lib().ssamd_kernel_name(i).decode(): ms[i] / args.steps for i in range(_native.K_COUNT) if launches[i]},
         }
-        if world == 1 and not args.consistent:
+        if world == 1 and not args.consistent and args.with_alternate:
             # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
             alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
                                        alternate=True)
