@@ -138,26 +138,40 @@ class StripContext:
 
         ctx = StripContext(matcher, height, width, rank, world_size, device)
         full = ctx.step(own_left, own_right)        # full [height, width] int16 map on every rank
+
+    With the nccl (RCCL) backend all messages move device to device.  With gloo and a GPU `device`
+    (functional tests of the multi-process flow on a box without RCCL peers) the messages are staged
+    through host buffers; the kernels still run on `device`.
     """
 
     def __init__(self, matcher, height, width, rank, world_size, device, group=None):
         import torch
+        import torch.distributed as dist
         self.matcher, self.H, self.W = matcher, int(height), int(width)
         self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.device = torch.device(device)
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.flat_gather = backend == "nccl"                  # gloo has no all_gather_into_tensor
+        self.staged = backend == "gloo" and self.device.type != "cpu"
+        cdev = torch.device("cpu") if self.staged else self.device          # where messages live
         self.pad = int(matcher.winSize) // 2
         self.r0, self.r1 = strip_bounds(self.H, self.world, self.rank)
         self.h0, self.h1 = halo_bounds(self.H, self.r0, self.r1, self.pad)
-        self.subL = torch.zeros((self.h1 - self.h0, self.W, 3), dtype=torch.uint8, device=device)
+        self.subL = torch.zeros((self.h1 - self.h0, self.W, 3), dtype=torch.uint8, device=self.device)
         self.subR = torch.zeros_like(self.subL)
         mine = [t for t in transfer_plan(self.H, self.world, self.pad) if self.rank in (t[0], t[1])]
         self.sends = [(dst, lo - self.r0, hi - self.r0) for src, dst, lo, hi in mine if src == self.rank]
         self.recvs = [(src, lo - self.h0, hi - self.h0) for src, dst, lo, hi in mine if dst == self.rank]
-        self.send_bufs = [(torch.empty((hi - lo, self.W, 3), dtype=torch.uint8, device=device),
-                           torch.empty((hi - lo, self.W, 3), dtype=torch.uint8, device=device)) for _, lo, hi in self.sends]
+
+        def pair(n):
+            return (torch.empty((n, self.W, 3), dtype=torch.uint8, device=cdev),
+                    torch.empty((n, self.W, 3), dtype=torch.uint8, device=cdev))
+        self.send_bufs = [pair(hi - lo) for _, lo, hi in self.sends]
+        self.recv_bufs = [pair(hi - lo) for _, lo, hi in self.recvs] if self.staged else None
         self.rows_max = -(-self.H // self.world)
-        self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=device)
-        self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=device)
-        self.full = torch.empty((self.H, self.W), dtype=torch.int16, device=device)
+        self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=cdev)
+        self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=cdev)
+        self.full = torch.empty((self.H, self.W), dtype=torch.int16, device=self.device)
 
     def step(self, own_left, own_right, gather=True):
         import torch
@@ -172,11 +186,16 @@ class StripContext:
                 br.copy_(own_right[lo:hi])
                 ops.append(dist.P2POp(dist.isend, bl, dst, group=self.group))
                 ops.append(dist.P2POp(dist.isend, br, dst, group=self.group))
-            for src, lo, hi in self.recvs:
-                ops.append(dist.P2POp(dist.irecv, self.subL[lo:hi], src, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, self.subR[lo:hi], src, group=self.group))
+            for k, (src, lo, hi) in enumerate(self.recvs):
+                tl, tr = self.recv_bufs[k] if self.staged else (self.subL[lo:hi], self.subR[lo:hi])
+                ops.append(dist.P2POp(dist.irecv, tl, src, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, tr, src, group=self.group))
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            if self.staged:
+                for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
+                    self.subL[lo:hi].copy_(tl)
+                    self.subR[lo:hi].copy_(tr)
         strip = self.matcher._compute_device(self.subL, self.subR, out_row0=o0, out_rows=self.r1 - self.r0)
         if not gather:
             return strip
@@ -184,12 +203,12 @@ class StripContext:
             return strip
         self.padded[:strip.shape[0]].copy_(strip)
         # int16 is not an RCCL collective dtype: gather the strips as bytes
-        if dist.get_backend(self.group) == "nccl":
+        if self.flat_gather:
             dist.all_gather_into_tensor(self.gathered.view(torch.uint8), self.padded.view(torch.uint8), group=self.group)
-        else:                                    # gloo (CPU tests) has no flat all-gather
+        else:
             parts = list(self.gathered.view(torch.uint8).unbind(0))
             dist.all_gather(parts, self.padded.view(torch.uint8), group=self.group)
-        if self.H == self.rows_max * self.world:
+        if self.H == self.rows_max * self.world and not self.staged:
             return self.gathered.view(self.H, self.W)
         for r in range(self.world):
             a, b = strip_bounds(self.H, self.world, r)
