@@ -148,3 +148,18 @@ def test_alternate_fuzz_vs_restatement(case, ss):
         if not (np.isfinite(cg) and abs(cg - cw) <= 1e-6 * max(1.0, abs(cw))):
             bad += 1
     assert bad == 0, (case, bad)
+
+
+def test_alternate_with_several_disparity_chunks_goes_through_the_key_path(ss, golden_inputs):
+    """a forced small tile splits the disparity range over several workgroups: the even rows are then merged
+    through the WTA keys and decoded, instead of being written by the aggregation kernel -- same map"""
+    import os
+    a, b = golden_inputs("synth_96x128")
+    m = ss.passive.StereoASW(winSize=21, maxDisparity=39, alternate=True)
+    want = m.compute(a, b)
+    os.environ["SSAMD_ASW_GEOM"] = "6,5,8"          # Dc = 20: two chunks for 40 disparities, chunked tap staging
+    try:
+        got = m.compute(a, b)
+    finally:
+        del os.environ["SSAMD_ASW_GEOM"]
+    assert np.array_equal(got, want)
