@@ -34,15 +34,17 @@
 
 namespace ssamd {
 
-static constexpr int ASW_RX = 8;      // columns per thread
+static constexpr int ASW_RX = 8;      // columns per thread of the default register tile (template parameter RX: 8 or 4)
 static constexpr int ASW_RD = 4;      // disparities per thread (one packed dword of e per row)
-static constexpr int ASW_NWR = (ASW_RX + ASW_RD - 1 + 3) / 4 * 4;   // right weights read per tap column (float4 granules)
 static constexpr int ASW_WB = 4;       // support weights evaluated side by side in the build phase
 static constexpr int ASW_MAX_THREADS = 768;
-static_assert(ASW_RX == 8 && ASW_RD == 4 && ASW_NWR == 12, "the main loop is unrolled for an 8x4 register tile");
+// right weights read per tap column (float4 granules): the RX + RD - 1 centres x - d of the register tile
+__host__ __device__ constexpr int asw_nwr(int rx) { return (rx + ASW_RD - 1 + 3) / 4 * 4; }
+static_assert(ASW_RD == 4 && asw_nwr(8) == 12 && asw_nwr(4) == 8, "the main loop is unrolled for 8x4 and 4x4 register tiles");
 
 struct AswGeom {
     int Tx, XG, DG, Dc, nchunks, threads;
+    int Rx;                      // columns per thread: 8, or 4 for small disparity ranges (twice the threads per column)
     int nL, nR, nRc, SR, Se, emask;
     int SL, hL, hR;              // wL row stride and the half offsets of the parity-split wL / wR rows
     int wseg, wlen;              // weight build: tap columns (of a chunk) split in wseg segments of wlen
@@ -95,14 +97,14 @@ __device__ __forceinline__ void asw_row_unpack(AswRow &row, const uint32_t packe
 
 // RX*RD taps of one tap column.  ROT: window slot of the thread's first column (slots rotate
 // by one per tap column; the rotation is resolved at compile time by unrolling RX columns).
-template <int ROT>
-__device__ __forceinline__ void asw_taps(float (&accN)[ASW_RX][ASW_RD], float (&accS)[ASW_RX][ASW_RD],
-                                         const float (&wl)[ASW_RX], const float (&wr)[ASW_NWR],
-                                         const AswRow (&win)[ASW_RX])
+template <int RX, int ROT>
+__device__ __forceinline__ void asw_taps(float (&accN)[RX][ASW_RD], float (&accS)[RX][ASW_RD],
+                                         const float (&wl)[RX], const float (&wr)[asw_nwr(RX)],
+                                         const AswRow (&win)[RX])
 {
 #pragma unroll
-    for (int xi = 0; xi < ASW_RX; ++xi) {
-        const AswRow &row = win[(ROT + xi) % ASW_RX];
+    for (int xi = 0; xi < RX; ++xi) {
+        const AswRow &row = win[(ROT + xi) % RX];
 #pragma unroll
         for (int di = 0; di < ASW_RD; ++di) {
             const float w = wl[xi] * wr[xi - di + ASW_RD - 1];
@@ -140,15 +142,20 @@ __device__ __forceinline__ int asw_split_pos(int c, int half)
 // e tile addressing: rows of Se bytes (Se = 4 * power of two >= DG), one dword (RD = 4 disparities)
 // per disparity group; the dword slot of group dg in row ul is XOR-swizzled with (ul / RX) so that
 // the lanes of a wave (consecutive xg, rows RX apart) read distinct banks.
+template <int RX>
 __device__ __forceinline__ int asw_e_offset(int ul, int slot, int Se, int emask)
 {
-    return ul * Se + ((slot ^ ((ul / ASW_RX) & emask)) << 2);
+    return ul * Se + ((slot ^ ((ul / RX) & emask)) << 2);
 }
 
 // CHUNKED: the tap columns of a window row are staged g.JC at a time (see the loop over jc below).
-template <bool WITH_COSTS, bool CHUNKED>
-__global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const AswArgs A)
+// RX: columns per thread.  8 is the throughput tile (168 VGPRs, 3 waves per SIMD).  4 halves the columns and
+// the accumulators per thread: twice the threads per tile column and 4 waves per SIMD, for small disparity
+// ranges where few threads share a weight row and LDS capacity, not VGPRs, limits the resident waves.
+template <bool WITH_COSTS, bool CHUNKED, int RX = ASW_RX>
+__global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregate_kernel(const AswArgs A)
 {
+    constexpr int NWR = asw_nwr(RX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AswGeom &g = A.g;
     float *const wL = reinterpret_cast<float *>(smem + g.off_wL);
@@ -192,9 +199,9 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     // lanes of a wave run along x (xg fastest): their wL / wR reads are consecutive 16-byte
     // slots (conflict-free ds_read_b128 for any lane grouping)
 
-    float accN[ASW_RX][ASW_RD], accS[ASW_RX][ASW_RD];
+    float accN[RX][ASW_RD], accS[RX][ASW_RD];
 #pragma unroll
-    for (int a = 0; a < ASW_RX; ++a)
+    for (int a = 0; a < RX; ++a)
 #pragma unroll
         for (int b = 0; b < ASW_RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
 
@@ -267,8 +274,8 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                     lo |= min(__builtin_amdgcn_sad_u8(lp, rp[-k], 0u), 40u) << (8 * k);
                     hi |= min(__builtin_amdgcn_sad_u8(lp, rp[-4 - k], 0u), 40u) << (8 * k);
                 }
-                *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp, Se, emask)) = lo;
-                if (2 * sp + 1 < g.DG) *reinterpret_cast<uint32_t *>(eT + asw_e_offset(ul, 2 * sp + 1, Se, emask)) = hi;
+                *reinterpret_cast<uint32_t *>(eT + asw_e_offset<RX>(ul, 2 * sp, Se, emask)) = lo;
+                if (2 * sp + 1 < g.DG) *reinterpret_cast<uint32_t *>(eT + asw_e_offset<RX>(ul, 2 * sp + 1, Se, emask)) = hi;
                 ul += e_r; sp += e_q;
                 if (ul >= nL) { ul -= nL; ++sp; }
             }
@@ -281,15 +288,15 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
         // (x - d >= 0, d <= maxDisparity, x < W); waves whose lanes are all outside (left image border,
         // padded disparities) skip the aggregation -- wave-uniform, decided once per window row
         const int xg = tidm % g.XG, dg = tidm / g.XG;
-        const bool tile_live = tidm < g.XG * g.DG && x0 + ASW_RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
-                               x0 + ASW_RX * xg + ASW_RX - 1 - (dlo + ASW_RD * dg) >= 0;
+        const bool tile_live = tidm < g.XG * g.DG && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
+                               x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
         const bool run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
-        const unsigned char *erow = eT + (ASW_RX * xg) * Se;
+        const unsigned char *erow = eT + (RX * xg) * Se;
         // swizzled dword slot of this thread's disparity group: depends on row / RX only, i.e. it
         // changes once per RX tap columns (rows ul0 .. ul0+RX-1 share slot0)
         int q = xg;
         int slotA = (dg ^ (q & emask)) << 2;
-        AswRow ew[ASW_RX];
+        AswRow ew[RX];
 
         for (int jc = 0; jc < win; jc += JC) {
             const int jend = min(win, jc + JC);
@@ -352,44 +359,51 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
             if (run) {
                 if (jc == 0) {
 #pragma unroll
-                    for (int n = 0; n < ASW_RX - 1; ++n) {
+                    for (int n = 0; n < RX - 1; ++n) {
                         asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow + slotA));
                         erow += Se;
                     }
                 }
                 // running LDS pointers (advanced by one tap column per step) keep the address arithmetic at
                 // ~4 VALU ops per step and nothing step-specific live across the loop
-                const float *wlp = wL + rb * g.SL + ASW_RX / 2 * xg;      // even block of the thread's columns; odd block at + hL
-                // right weights: ASW_NWR/4 consecutive 4-float blocks starting at block b0 (parity-split rows)
-                const int b0 = (ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD) >> 2;
+                // RX = 8: even block of the thread's columns, odd block at + hL;  RX = 4: the thread's single block
+                const float *wlp = wL + rb * g.SL + (RX == 8 ? RX / 2 * xg : (xg & 1) * g.hL + ((xg >> 1) << 2));
+                // right weights: NWR/4 consecutive 4-float blocks starting at block b0 (parity-split rows)
+                const int b0 = (RX * xg - ASW_RD * dg + Dc - ASW_RD) >> 2;
                 const float *wrp0 = wR + rb * SR + (b0 & 1) * g.hR + ((b0 >> 1) << 2);
                 const float *wrp1 = wR + rb * SR + ((b0 + 1) & 1) * g.hR + (((b0 + 1) >> 1) << 2);
                 const float *wrp2 = wR + rb * SR + (b0 & 1) * g.hR + (((b0 + 2) >> 1) << 2);
-                for (int j0 = jc; j0 < jend; j0 += ASW_RX) {
+                for (int j0 = jc; j0 < jend; j0 += RX) {
                     const int slotB = (dg ^ ((q + 1) & emask)) << 2;
 #define SSAMD_STEP(JJ, SLOT)                                                                        \
     if (j0 + (JJ) < jend) {                                                                         \
-        asw_row_unpack(ew[((JJ) + ASW_RX - 1) % ASW_RX], *reinterpret_cast<const uint32_t *>(erow + (SLOT))); \
+        asw_row_unpack(ew[((JJ) + RX - 1) % RX], *reinterpret_cast<const uint32_t *>(erow + (SLOT))); \
         erow += Se;                                                                                 \
-        float wl[ASW_RX], wr[ASW_NWR];                                                              \
+        float wl[RX], wr[NWR];                                                              \
         {                                                                                           \
             const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                              \
-            const float4 v1 = *reinterpret_cast<const float4 *>(wlp + g.hL);                       \
             wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                                 \
-            wl[4] = v1.x; wl[5] = v1.y; wl[6] = v1.z; wl[7] = v1.w;                                 \
+            if constexpr (RX == 8) {                                                                \
+                const float4 v1 = *reinterpret_cast<const float4 *>(wlp + g.hL);                   \
+                wl[RX - 4] = v1.x; wl[RX - 3] = v1.y; wl[RX - 2] = v1.z; wl[RX - 1] = v1.w;         \
+            }                                                                                       \
             const float4 r0 = *reinterpret_cast<const float4 *>(wrp0);                             \
             const float4 r1 = *reinterpret_cast<const float4 *>(wrp1);                             \
-            const float4 r2 = *reinterpret_cast<const float4 *>(wrp2);                             \
             wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                                 \
             wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                                 \
-            wr[8] = r2.x; wr[9] = r2.y; wr[10] = r2.z; wr[11] = r2.w;                               \
+            if constexpr (RX == 8) {                                                                \
+                const float4 r2 = *reinterpret_cast<const float4 *>(wrp2);                         \
+                wr[NWR - 4] = r2.x; wr[NWR - 3] = r2.y; wr[NWR - 2] = r2.z; wr[NWR - 1] = r2.w;     \
+            }                                                                                       \
         }                                                                                           \
         wlp += g.SL; wrp0 += SR; wrp1 += SR; wrp2 += SR;                                            \
-        asw_taps<(JJ)>(accN, accS, wl, wr, ew);                                                     \
+        asw_taps<RX, (JJ)>(accN, accS, wl, wr, ew);                                                 \
     }
                     // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards
                     SSAMD_STEP(0, slotA) SSAMD_STEP(1, slotB) SSAMD_STEP(2, slotB) SSAMD_STEP(3, slotB)
-                    SSAMD_STEP(4, slotB) SSAMD_STEP(5, slotB) SSAMD_STEP(6, slotB) SSAMD_STEP(7, slotB)
+                    if constexpr (RX == 8) {
+                        SSAMD_STEP(RX - 4, slotB) SSAMD_STEP(RX - 3, slotB) SSAMD_STEP(RX - 2, slotB) SSAMD_STEP(RX - 1, slotB)
+                    }
 #undef SSAMD_STEP
                     slotA = slotB;
                     ++q;
@@ -404,12 +418,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
     asm volatile("" : "+v"(tidf));
     if (tidf < g.XG * g.DG) {
         const int xg = tidf % g.XG, dg = tidf / g.XG;
-        u64 diag[ASW_RX + ASW_RD - 1];
+        u64 diag[RX + ASW_RD - 1];
 #pragma unroll
-        for (int k = 0; k < ASW_RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;
+        for (int k = 0; k < RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;
 #pragma unroll
-        for (int xi = 0; xi < ASW_RX; ++xi) {
-            const int x = x0 + ASW_RX * xg + xi;
+        for (int xi = 0; xi < RX; ++xi) {
+            const int x = x0 + RX * xg + xi;
             u64 bl = KEY_NONE;
 #pragma unroll
             for (int di = 0; di < ASW_RD; ++di) {
@@ -424,12 +438,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_kernel(const
                         A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
                 }
             }
-            if (bl != KEY_NONE) atomicMin(&bestL[ASW_RX * xg + xi], bl);
+            if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);
         }
         if (A.keyR) {
-            const int base = ASW_RX * xg - ASW_RD * dg + Dc - ASW_RD;
+            const int base = RX * xg - ASW_RD * dg + Dc - ASW_RD;
 #pragma unroll
-            for (int k = 0; k < ASW_RX + ASW_RD - 1; ++k)
+            for (int k = 0; k < RX + ASW_RD - 1; ++k)
                 if (diag[k] != KEY_NONE) atomicMin(&bestR[base + k], diag[k]);
         }
     }

@@ -174,22 +174,23 @@ int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ ASW geometry
-bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20)
+bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20, int Rx = ASW_RX)
 {
+    g.Rx = Rx;
     g.JC = JC >= win ? win : JC;                 // tap columns staged per chunk; win = the whole row at once
     const int wrows = g.JC < win ? 2 * g.JC : win;   // chunk buffers alternate
     const int wcols = g.JC;                      // tap columns a weight-build pass covers
 
     const int p = win / 2;
     g.XG = XG; g.DG = DG;
-    g.Tx = ASW_RX * XG; g.Dc = ASW_RD * DG;
+    g.Tx = Rx * XG; g.Dc = ASW_RD * DG;
     g.threads = round_up(XG * DG, 64);
     g.nL = g.Tx + 2 * p;
     g.nRc = g.Tx + g.Dc - 1;
     g.nR = g.nRc + 2 * p;
     // parity-split rows (asw_split_pos): two halves of ceil(n/8)*4 floats; +1 block so that the halves
     // start on different banks phases and reads one block past the end stay inside the row
-    g.hL = (g.Tx / 8) * 4 + 4;
+    g.hL = ((g.Tx + 7) / 8) * 4 + 4;
     g.SL = 2 * g.hL;
     g.hR = ((g.nRc + 4 + 7) / 8) * 4 + 4;
     g.SR = 2 * g.hR;
@@ -237,12 +238,13 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 <<
 //     workgroups over the 256 CUs are charged as lost throughput.
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
-    // tuning hook: SSAMD_ASW_GEOM="XG,DG" forces the tile shape (experiments only)
+    // tuning hook: SSAMD_ASW_GEOM="XG,DG[,JC[,RX]]" forces the tile shape (experiments and tests only)
     if (const char *env = getenv("SSAMD_ASW_GEOM")) {
-        int XG = 0, DG = 0, JCe = 1 << 20;
-        if (sscanf(env, "%d,%d,%d", &XG, &DG, &JCe) >= 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS) {
-            if (JCe <= 0 || JCe % ASW_RX) JCe = 1 << 20;
-            if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
+        int XG = 0, DG = 0, JCe = 1 << 20, Rx = ASW_RX;
+        if (sscanf(env, "%d,%d,%d,%d", &XG, &DG, &JCe, &Rx) >= 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS &&
+            (Rx == 8 || Rx == 4)) {
+            if (JCe <= 0 || JCe % Rx) JCe = 1 << 20;
+            if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe, Rx)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
             return SSAMD_OK;
         }
@@ -255,17 +257,25 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
         const int DG = round_up(per, ASW_RD) / ASW_RD;
         if (DG > 128) continue;
         if ((nD + DG * ASW_RD - 1) / (DG * ASW_RD) != nch) continue;
-        const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + ASW_RX - 1) / ASW_RX);
+        // register tile 8x4 (168 VGPRs: 3 waves per SIMD), or 4x4 (<= 128 VGPRs: 4 waves per SIMD, twice the
+        // threads per tile column) for small disparity ranges, where LDS capacity bounds the resident waves
+        // (measured, 1080p / win 35: D 0..16 16.7 -> 10.5 ms, D 0..32 14.3 -> 13.2 ms, D 0..64 no gain)
+        for (int Rx : {8, 4}) {
+        if (Rx == 4 && nD > 40) continue;
+        const int max_wps = Rx == 8 ? 3 : 4;
+        const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + Rx - 1) / Rx);
         for (int XG = xg_cap; XG >= 1; --XG)
-        for (int JC : {1 << 20, 16, 8}) {
-            if (JC < (1 << 20) && JC >= win) continue;
+        for (int JC : {1 << 20, 16, 8, 4}) {
+            if (JC < (1 << 20) && (JC >= win || JC % Rx)) continue;
             AswGeom g;
-            if (!asw_layout(g, win, XG, DG, 160 * 1024, JC)) continue;
+            if (!asw_layout(g, win, XG, DG, 160 * 1024, JC, Rx)) continue;
             g.nchunks = nch;
             const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
-            const int k = std::min(3 / per_simd, (160 * 1024) / g.lds_bytes);
+            const int k = std::min(max_wps / per_simd, (160 * 1024) / g.lds_bytes);
             if (k < 1) continue;
-            const double M = (double)win * ASW_RX * ASW_RD * c_tap;
+            // per-thread aggregation cycles of one window row; the 4-column tile spends the same address and
+            // e-row work on half the taps
+            const double M = (double)win * Rx * ASW_RD * (Rx == 8 ? c_tap : c_tap * 1.15);
             const int ncen = g.Tx + g.nRc;
             const int njc = (win + g.JC - 1) / g.JC;                 // weight-build passes (= barriers) per window row
             const double B = (double)njc * ((ncen * g.wseg + g.threads - 1) / g.threads) * (round_up(g.wlen, ASW_WB) + 2) * c_w +
@@ -282,8 +292,10 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
             // resident waves hide less latency (measured: 2 waves/SIMD ~0.85x, 1 wave/SIMD ~0.6x of 3)
             const int wps = k * per_simd;
             const double occ = wps >= 3 ? 1.0 : (wps == 2 ? 0.85 : 0.6);
-            const double score = (double)XG * DG / per_simd * occ * (M / (M + B)) * d_util * x_util * tail * overlap;
+            const double useful = (double)win * Rx * ASW_RD * c_tap;        // = M for the 8-column tile
+            const double score = (double)XG * DG / per_simd * occ * (useful / (M + B)) * d_util * x_util * tail * overlap;
             if (score > best_score) { best_score = score; best = g; found = true; }
+        }
         }
         if (DG <= 2) break;
     }
@@ -386,6 +398,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         const bool chunked = a.g.JC < win;
         auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
                             : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
+        if (a.g.Rx == 4)
+            kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true, 4> : asw_aggregate_kernel<false, true, 4>)
+                           : (d_costs ? asw_aggregate_kernel<true, false, 4> : asw_aggregate_kernel<false, false, 4>);
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.g.lds_bytes));
         {
             Timed t(c, s, SSAMD_K_ASW_AGG);

@@ -143,12 +143,12 @@ def test_asw_degenerate_ranges(ss, golden_inputs):
     assert np.array_equal(ss.passive.StereoASW(**p).compute(flat, flat), oracle.asw(flat, flat, **p))
 
 
-@pytest.mark.parametrize("geom", ["6,5,8", "10,9,16", "3,9,8", "12,3,8"])
+@pytest.mark.parametrize("geom", ["6,5,8", "10,9,16", "3,9,8", "12,3,8", "12,5,0,4", "7,9,8,4", "20,3,4,4", "5,10,12,4"])
 def test_asw_forced_geometries_and_chunked_staging_agree(geom, ss, golden_inputs):
     """every launch geometry (tile shape, tap-column chunking) computes the same sums in the same order:
     forced shapes via the SSAMD_ASW_GEOM tuning hook must reproduce the default result bit for bit"""
     a, b = golden_inputs("synth_96x128")
-    maxd = int(geom.split(",")[1]) * 4 - 1
+    maxd = int(geom.split(",")[1]) * 4 - 1        # geom = XG,DG[,JC[,RX]]: 4-column register tiles as well
     m = ss.passive.StereoASW(winSize=21, maxDisparity=maxd, minDisparity=0, consistent=True)
     want = m.compute(a, b)
     os.environ["SSAMD_ASW_GEOM"] = geom
