@@ -10,7 +10,7 @@
 // Work decomposition
 //   workgroup  = (image row y, tile of Tx left columns, chunk of Dc disparities)
 //   thread     = register tile of RX=8 columns x RD=4 disparities, 2 fp32 accumulators
-//                (N, S' -- see below) per (x,d) pair
+//                (N, S' -- see below) per (x,d) pair (RX=4 instantiation for small disparity ranges)
 //   outer loop = the window rows i (tap row r = y - pad + i).  Per window row the
 //                workgroup stages the pixels it needs in LDS (prefetched one row ahead) and
 //                builds, in LDS,
