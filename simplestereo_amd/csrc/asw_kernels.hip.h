@@ -324,8 +324,36 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
                     const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
                     // batches of ASW_WB independent evaluations: all LDS reads first, then the dependent
                     // chains (sub, fma, v_sqrt, v_exp, mul) side by side -- a single chain is ~150 cycles of
-                    // latency, and during this phase every wave of the group is in the same loop
-                    for (int j = jc + sgm * g.wlen; j < j1; j += ASW_WB) {
+                    // latency, and during this phase every wave of the group is in the same loop.  Whole
+                    // batches walk running pointers (staged pixels, proximity row, output column); only the
+                    // last, partial batch of a segment pays for clamped indices.
+                    int j = jc + sgm * g.wlen;
+                    const float4 *sp = seg + j;
+                    const float *pp = prow + j;
+                    float *wp = wout + j * stride;
+                    int col = col0 + j;
+                    const int stride4 = ASW_WB * stride;
+                    for (; j + ASW_WB <= j1; j += ASW_WB, sp += ASW_WB, pp += ASW_WB, wp += stride4, col += ASW_WB) {
+                        float4 tp[ASW_WB];
+                        float pr[ASW_WB], wv[ASW_WB];
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) { tp[u] = sp[u]; pr[u] = pp[u]; }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                            wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                        }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
+                            wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                        }
+                    }
+                    if (j < j1) {
                         float4 tp[ASW_WB];
                         float pr[ASW_WB], wv[ASW_WB];
 #pragma unroll
