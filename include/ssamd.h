@@ -91,15 +91,17 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
  * disparity map on every other pixel with the traditional algorithm, then fill the remaining
  * pixels using left-right disparity boundaries"); opt-in, never the default.  Even image rows are
  * matched exactly; a pixel of an odd row searches only the disparities between the results of the
- * pixels above and below it (copied when they agree), with the exact ASW cost.  Whole images only,
- * no consistency pass.  Same buffers and error codes as ssamd_asw / ssamd_asw_device. */
+ * pixels above and below it (copied when they agree), with the exact ASW cost.  With `consistent`
+ * the even rows also get the right-referenced pass, the left-right check and the occlusion filling
+ * of ssamd_asw before the odd rows are derived from them.  Whole images only.  Same buffers and
+ * error codes as ssamd_asw / ssamd_asw_device. */
 int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width,
                         int winSize, int maxDisparity, int minDisparity,
-                        double gammaC, double gammaP,
+                        double gammaC, double gammaP, int consistent,
                         int16_t *disparity, int device);
 int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
                                int winSize, int maxDisparity, int minDisparity,
-                               double gammaC, double gammaP,
+                               double gammaC, double gammaP, int consistent,
                                int16_t *d_disparity, void *stream);
 
 /* ---- the steps either side of the matchers, on device --------- */

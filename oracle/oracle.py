@@ -82,7 +82,8 @@ def asw(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gamma
     return (out, costs) if return_costs else out
 
 
-def asw_alternate(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, exact_rows=None):
+def asw_alternate(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
+                  exact_rows=None):
     """CPU restatement of the alternate-rows ASW mode (simplestereo_amd/csrc/asw_alt_kernels.hip.h).
 
     The reference only sketches the idea (docstring todo, reference passive.py:43-46) -- there is no
@@ -91,10 +92,14 @@ def asw_alternate(img1, img2, winSize=35, maxDisparity=16, minDisparity=0, gamma
     rows = argmin of the reference's fp64 costs over the disparities between the results above and
     below (first minimum wins, as in _passive.cpp:90-93).  ``exact_rows``: optional [H,W] map whose even
     rows replace the oracle's own (to test the fill stage in isolation from fp32-vs-fp64 argmin ties
-    on the exact rows).  Returns (map, number of evaluated pixels)."""
+    on the exact rows).  ``consistent``: the even rows come from the consistent mode (left-right check and
+    occlusion filling of _passive.cpp:191-285); the odd rows are derived from them in the same way.
+    Returns (map, number of evaluated pixels)."""
     exact, costs = asw(img1, img2, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent=False,
                        hoist=True, return_costs=True) if maxDisparity >= minDisparity else (asw(
                            img1, img2, winSize, maxDisparity, minDisparity, gammaC, gammaP), None)
+    if consistent:
+        exact = asw(img1, img2, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent=True)
     out = np.array(exact if exact_rows is None else exact_rows, dtype=np.int32)
     H, W = out.shape
     evaluated = 0

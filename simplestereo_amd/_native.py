@@ -49,9 +49,9 @@ def lib():
     L.ssamd_gsw_device.restype = I
     L.ssamd_gsw_device.argtypes = [P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]
     L.ssamd_asw_alternate.restype = I
-    L.ssamd_asw_alternate.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
+    L.ssamd_asw_alternate.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
     L.ssamd_asw_alternate_device.restype = I
-    L.ssamd_asw_alternate_device.argtypes = [P, P, I, I, I, I, I, D, D, P, P]
+    L.ssamd_asw_alternate_device.argtypes = [P, P, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_costs.restype = I
     L.ssamd_asw_costs.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
     L.ssamd_bgr2lab.restype = I

@@ -356,8 +356,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
-    if (alternate && (consistent || d_costs || row0 != 0 || rows != H))
-        return fail(SSAMD_EINVAL, "the alternate-rows mode takes the whole image and neither consistent nor a cost dump");
+    if (alternate && (d_costs || row0 != 0 || rows != H))
+        return fail(SSAMD_EINVAL, "the alternate-rows mode takes the whole image and no cost dump");
     if (rows == 0) return SSAMD_OK;
     ScratchOrder order(c, s);
     const int p = win / 2, nD = maxD - minD + 1;
@@ -686,17 +686,17 @@ int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width, i
 }
 
 int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
-                        int minDisparity, double gammaC, double gammaP, int16_t *disparity, int device)
+                        int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
     if (!disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, disparity, nullptr,
-                    device, true);
+    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent, disparity,
+                    nullptr, device, true);
 }
 
 int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int winSize,
-                               int maxDisparity, int minDisparity, double gammaC, double gammaP, int16_t *d_disparity,
-                               void *stream)
+                               int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
+                               int16_t *d_disparity, void *stream)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
     if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
@@ -704,7 +704,7 @@ int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int
     int rc = get_ctx(-1, &c);
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC,
-                           gammaP, 0, d_disparity, nullptr, (hipStream_t)stream, true);
+                           gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream, true);
 }
 
 int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,

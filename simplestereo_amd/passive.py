@@ -133,7 +133,8 @@ class StereoASW():
         row exactly and let each pixel of the rows in between search only the disparities between the
         results above and below it (copied when they agree).  About twice as fast; not the reference's
         output (about 2-3 % of the pixels differ on Tsukuba, bad-1.0 against the ground truth does not
-        get worse).  Whole images only; cannot be combined with ``consistent`` (default False).
+        get worse).  With ``consistent`` the exact rows go through the left-right check and the occlusion
+        filling first.  Whole images only (default False).
     consistent : bool
         Also match with the right image as reference, invalidate left pixels whose match does
         not agree, and fill each invalid run with the smaller of its two valid neighbours
@@ -162,8 +163,6 @@ class StereoASW():
     def _alternate(self, cons, whole_image=True):
         if not getattr(self, "alternate", False):
             return False
-        if cons:
-            raise ValueError("alternate=True cannot be combined with consistent=True")
         if not whole_image:
             raise ValueError("alternate=True needs the whole image (no row strips)")
         return True
@@ -190,7 +189,7 @@ class StereoASW():
         out = np.empty((H, W), np.int16)
         try:
             if self._alternate(cons):
-                _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp,
+                _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
                                                       out.ctypes.data, dev))
                 return out
             _native.check(lib.ssamd_asw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
@@ -217,7 +216,7 @@ class StereoASW():
             try:
                 if alt:
                     _native.check(lib.ssamd_asw_alternate_device(a.data_ptr(), b.data_ptr(), H, W, win, maxd, mind,
-                                                                 gc, gp, out.data_ptr(), ctypes.c_void_p(stream)))
+                                                                 gc, gp, cons, out.data_ptr(), ctypes.c_void_p(stream)))
                     return out
                 _native.check(lib.ssamd_asw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
                                                    maxd, mind, gc, gp, cons, out.data_ptr(),

@@ -73,8 +73,6 @@ def test_alternate_device_tensors_edges_and_errors(ss, golden_inputs):
     # empty candidate ranges give x, as in the exact mode (_passive.cpp:54,98)
     e = ss.passive.StereoASW(winSize=5, maxDisparity=3, minDisparity=7, alternate=True).compute(a, b)
     assert np.array_equal(e, np.tile(np.arange(a.shape[1], dtype=np.int16), (a.shape[0], 1)))
-    with pytest.raises(ValueError, match="consistent"):
-        ss.passive.StereoASW(alternate=True, consistent=True, **p).compute(a, b)
     with pytest.raises(ValueError, match="whole image"):
         m._compute_device(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), out_row0=2, out_rows=6)
 
@@ -163,3 +161,21 @@ def test_alternate_with_several_disparity_chunks_goes_through_the_key_path(ss, g
     finally:
         del os.environ["SSAMD_ASW_GEOM"]
     assert np.array_equal(got, want)
+
+
+def test_alternate_with_consistency_check_on_the_exact_rows(ss, golden_inputs):
+    """consistent=True + alternate=True: the even rows are the consistent mode's rows (right-referenced pass,
+    left-right check, occlusion filling), the odd rows are derived from them by the bounded search"""
+    from oracle import oracle
+    a, b = golden_inputs("tsukuba")
+    a, b = np.ascontiguousarray(a[40:111]), np.ascontiguousarray(b[40:111])
+    p = dict(winSize=15, maxDisparity=16, consistent=True)
+    exact = ss.passive.StereoASW(**p).compute(a, b)
+    alt = ss.passive.StereoASW(alternate=True, **p).compute(a, b)
+    assert np.array_equal(alt[::2], exact[::2])
+    want, evaluated = oracle.asw_alternate(a, b, exact_rows=exact, **p)
+    diff = np.abs(alt[1::2].astype(np.int32) - want[1::2])
+    print("consistent+alternate: evaluated", evaluated, "odd rows exact %.5f" % (diff == 0).mean())
+    assert evaluated > 0 and (diff <= 1).mean() >= WITHIN1 and (diff == 0).mean() >= EXACT
+    want2, _ = oracle.asw_alternate(a, b, **p)
+    assert (np.abs(alt.astype(np.int32) - want2) <= 1).mean() >= 0.99     # LR fill amplifies rare argmin ties into runs
