@@ -157,3 +157,33 @@ def test_asw_forced_geometries_and_chunked_staging_agree(geom, ss, golden_inputs
     finally:
         del os.environ["SSAMD_ASW_GEOM"]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("H,W,maxd,shift", [(1080, 1920, 192, 150), (2160, 4096, 256, 233)])
+def test_asw_full_size_configs_3_and_5_known_shift_and_strip_invariance(H, W, maxd, shift, ss):
+    """BASELINE configs 3 and 5 at full size, through size-independent properties: (1) a right image that is the
+    left image moved by a constant shift has aggregated cost exactly 0 at d = shift wherever the window and its
+    shifted copy are inside the image -> the map must equal the shift there (ties -> smallest d cannot
+    undercut it on a textured image); (2) rows matched as a strip carrying its halo equal the same rows of the
+    whole frame bit for bit; (3) determinism."""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    L = make_pair(H, W, maxd, 5)[0]
+    R = np.zeros_like(L)
+    R[:, :W - shift] = L[:, shift:]
+    R[:, W - shift:] = L[:, :shift]                      # wrapped columns: not inspected
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(winSize=35, maxDisparity=maxd)
+    d = m.compute(tL, tR)
+    torch.cuda.synchronize()
+    dn = d.cpu().numpy()
+    pad = 17
+    inner = dn[:, shift + pad:W - pad]                    # right taps x - shift - pad .. stay inside [0, W - shift)
+    frac = float((inner == shift).mean())
+    print("%dx%d D0..%d: %.5f of the interior pixels at the known shift %d" % (W, H, maxd, frac, shift))
+    assert frac >= 0.9999
+    assert torch.equal(m.compute(tL, tR), d)
+    r0, rows = H // 2 - 20, 45
+    h0, h1 = r0 - pad, r0 + rows + pad
+    strip = m._compute_device(tL[h0:h1].contiguous(), tR[h0:h1].contiguous(), out_row0=r0 - h0, out_rows=rows)
+    assert torch.equal(strip, d[r0:r0 + rows])
