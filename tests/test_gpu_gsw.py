@@ -130,3 +130,28 @@ def test_gsw_forced_geometries_and_strip_heights_agree(geom, ss, golden_cases, g
     assert np.array_equal(got, base)
     assert np.array_equal(got_odd, odd)
     assert np.array_equal(got, maps["G6d"])     # G6d = these parameters on this pair, from the reference
+
+
+def test_gsw_1080p_config4_known_shift_and_strip_invariance(ss):
+    """BASELINE config 4 at full size through size-independent properties: a right image that is the left image
+    moved by a constant shift costs exactly 0 at d = shift in both passes wherever the window and its shifted
+    copy are inside the image, so the (left-right checked) map equals the shift there; and rows matched as a
+    strip carrying its halo equal the rows of the whole frame bit for bit."""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    H, W, maxd, shift, pad = 1080, 1920, 192, 141, 5
+    L = make_pair(H, W, maxd, 7)[0]
+    R = np.zeros_like(L)
+    R[:, :W - shift] = L[:, shift:]
+    R[:, W - shift:] = L[:, :shift]
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoGSW(maxDisparity=maxd)
+    d = m.compute(tL, tR)
+    inner = d[:, shift + pad:W - pad].cpu().numpy()
+    frac = float((inner == shift).mean())
+    print("GSW 1920x1080 D0..192: %.5f of the interior pixels at the known shift %d" % (frac, shift))
+    assert frac >= 0.9999
+    r0, rows = 500, 37
+    h0, h1 = r0 - pad, r0 + rows + pad
+    strip = m._compute_device(tL[h0:h1].contiguous(), tR[h0:h1].contiguous(), out_row0=r0 - h0, out_rows=rows)
+    assert torch.equal(strip, d[r0:r0 + rows])
