@@ -259,9 +259,10 @@ int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
         if ((nD + DG * ASW_RD - 1) / (DG * ASW_RD) != nch) continue;
         // register tile 8x4 (168 VGPRs: 3 waves per SIMD), or 4x4 (<= 128 VGPRs: 4 waves per SIMD, twice the
         // threads per tile column) for small disparity ranges, where LDS capacity bounds the resident waves
-        // (measured, 1080p / win 35: D 0..16 16.7 -> 10.5 ms, D 0..32 14.3 -> 13.2 ms, D 0..64 no gain)
+        // (measured, 1080p / win 35: D 0..16 16.7 -> 10.5 ms, D 0..32 14.3 -> 13.2 ms, D 0..47 17.2 -> 14.7 ms,
+        //  D 0..64 no gain)
         for (int Rx : {8, 4}) {
-        if (Rx == 4 && nD > 40) continue;
+        if (Rx == 4 && nD > 56) continue;
         const int max_wps = Rx == 8 ? 3 : 4;
         const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + Rx - 1) / Rx);
         for (int XG = xg_cap; XG >= 1; --XG)
