@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -236,7 +238,26 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 <<
 //     tiles; B shrinks with the tile (fewer window centres per (x,d) pair).
 //   - padding of the disparity range, idle lanes, partial x tiles and the last partial wave of
 //     workgroups over the 256 CUs are charged as lost throughput.
+int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD);
+
+// The search walks a few thousand candidate tiles (0.1-0.3 ms on the host): remember the answer per problem shape,
+// a video stream asks the same question every frame.  (Callers hold g_mutex.)
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
+{
+    static std::map<std::array<int, 4>, AswGeom> cache;
+    if (getenv("SSAMD_ASW_GEOM")) return asw_search_geometry(best, W, rows, win, nD);      // tuning hook: never cached
+    const std::array<int, 4> key{W, rows, win, nD};
+    auto it = cache.find(key);
+    if (it != cache.end()) { best = it->second; return SSAMD_OK; }
+    const int rc = asw_search_geometry(best, W, rows, win, nD);
+    if (rc == SSAMD_OK) {
+        if (cache.size() > 256) cache.clear();
+        cache[key] = best;
+    }
+    return rc;
+}
+
+int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
     // tuning hook: SSAMD_ASW_GEOM="XG,DG[,JC[,RX]]" forces the tile shape (experiments and tests only)
     if (const char *env = getenv("SSAMD_ASW_GEOM")) {
@@ -468,7 +489,24 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
 // Launch geometry of the GSW kernel: strip height Ty, XG x DG thread grid.  Relative cost model of one
 // strip, per thread: every image row of the strip pays the e tile once (c_e per element), every
 // (output row, window row) pair pays its weights (c_w per element) and its taps (c_tap per cell).
-int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)
+int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD);
+
+int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)      // cached like asw_choose_geometry
+{
+    static std::map<std::array<int, 4>, GswGeom> cache;
+    if (getenv("SSAMD_GSW_GEOM")) return gsw_search_geometry(best, W, rows, win, nD);
+    const std::array<int, 4> key{W, rows, win, nD};
+    auto it = cache.find(key);
+    if (it != cache.end()) { best = it->second; return SSAMD_OK; }
+    const int rc = gsw_search_geometry(best, W, rows, win, nD);
+    if (rc == SSAMD_OK) {
+        if (cache.size() > 256) cache.clear();
+        cache[key] = best;
+    }
+    return rc;
+}
+
+int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
 {
     if (const char *env = getenv("SSAMD_GSW_GEOM")) {           // experiment hook: "XG,DG,Ty"
         int XG = 0, DG = 0, Ty = 1;
