@@ -153,6 +153,13 @@ int ssamd_profile_reset(void);
 int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);
 const char *ssamd_kernel_name(int slot);
 
+/* Autotuning of the ASW launch geometry (off by default; also switched on by the environment variable
+ * SSAMD_AUTOTUNE=1).  When on, the first ssamd_asw* call for a problem shape (width, rows, winSize, number of
+ * disparities) times the best tile of every class of candidates on the call's own buffers -- about ten extra
+ * launches, once -- and later calls reuse the fastest.  The disparity maps do not depend on the geometry.
+ * Returns the previous setting. */
+int ssamd_autotune(int on);
+
 /* Launch geometry chosen for an ASW problem (for DESIGN.md / bench reporting).
  * out[0..7] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y, grid_z */
 int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);

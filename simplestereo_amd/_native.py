@@ -69,6 +69,8 @@ def lib():
     L.ssamd_profile_read.argtypes = [ctypes.POINTER(D), ctypes.POINTER(ctypes.c_longlong)]
     L.ssamd_kernel_name.restype = ctypes.c_char_p
     L.ssamd_kernel_name.argtypes = [I]
+    L.ssamd_autotune.restype = I
+    L.ssamd_autotune.argtypes = [I]
     L.ssamd_asw_geometry.restype = I
     L.ssamd_asw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
     L.ssamd_gsw_geometry.restype = I

@@ -238,27 +238,33 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 <<
 //     tiles; B shrinks with the tile (fewer window centres per (x,d) pair).
 //   - padding of the disparity range, idle lanes, partial x tiles and the last partial wave of
 //     workgroups over the 256 CUs are charged as lost throughput.
-int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD);
+int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::vector<AswGeom> *shortlist = nullptr);
 
 // The search walks a few thousand candidate tiles (0.1-0.3 ms on the host): remember the answer per problem shape,
 // a video stream asks the same question every frame.  (Callers hold g_mutex.)
+std::map<std::array<int, 4>, AswGeom> g_asw_geom_cache;
+std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached geometry was picked by measurement
+bool g_autotune = getenv("SSAMD_AUTOTUNE") != nullptr && atoi(getenv("SSAMD_AUTOTUNE")) != 0;
+
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
-    static std::map<std::array<int, 4>, AswGeom> cache;
     if (getenv("SSAMD_ASW_GEOM")) return asw_search_geometry(best, W, rows, win, nD);      // tuning hook: never cached
     const std::array<int, 4> key{W, rows, win, nD};
-    auto it = cache.find(key);
-    if (it != cache.end()) { best = it->second; return SSAMD_OK; }
+    auto it = g_asw_geom_cache.find(key);
+    if (it != g_asw_geom_cache.end()) { best = it->second; return SSAMD_OK; }
     const int rc = asw_search_geometry(best, W, rows, win, nD);
     if (rc == SSAMD_OK) {
-        if (cache.size() > 256) cache.clear();
-        cache[key] = best;
+        if (g_asw_geom_cache.size() > 256) { g_asw_geom_cache.clear(); g_asw_geom_tuned.clear(); }
+        g_asw_geom_cache[key] = best;
     }
     return rc;
 }
 
-int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD)
+// shortlist (autotuning): the best-scoring geometry of every structurally different class of candidates
+// (register tile, tap-column chunking, disparity chunks, waves per group), best classes first
+int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::vector<AswGeom> *shortlist)
 {
+    std::map<std::array<int, 4>, std::pair<double, AswGeom>> classes;
     // tuning hook: SSAMD_ASW_GEOM="XG,DG[,JC[,RX]]" forces the tile shape (experiments and tests only)
     if (const char *env = getenv("SSAMD_ASW_GEOM")) {
         int XG = 0, DG = 0, JCe = 1 << 20, Rx = ASW_RX;
@@ -317,9 +323,20 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD)
             const double useful = (double)win * Rx * ASW_RD * c_tap;        // = M for the 8-column tile
             const double score = (double)XG * DG / per_simd * occ * (useful / (M + B)) * d_util * x_util * tail * overlap;
             if (score > best_score) { best_score = score; best = g; found = true; }
+            if (shortlist) {
+                auto &slot = classes[{Rx, std::min(g.JC, 64), nch, waves}];
+                if (score > slot.first) slot = {score, g};
+            }
         }
         }
         if (DG <= 2) break;
+    }
+    if (shortlist && found) {
+        std::vector<std::pair<double, AswGeom>> v;
+        for (auto &kv : classes) v.push_back(kv.second);
+        std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        shortlist->clear();
+        for (size_t i = 0; i < v.size() && i < 10 && v[i].first > 0.6 * best_score; ++i) shortlist->push_back(v[i].second);
     }
     return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no ASW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
 }
@@ -388,9 +405,21 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
     // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
     AswArgs a;
-    if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, alternate ? (rows + 1) / 2 : rows, win, nD))) return rc;
-    const bool direct = nD >= 1 && a.g.nchunks == 1 && !consistent;
-    if (!direct || alternate) {                 // the alternate mode merges its odd-row jobs through the left keys
+    const int grows = alternate ? (rows + 1) / 2 : rows;              // workgroup rows: every row, or the even ones
+    if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, grows, win, nD))) return rc;
+    // Autotuning (ssamd_autotune): the first call for a problem shape times the best geometry of every class of
+    // candidates on the real buffers and keeps the fastest.  Every geometry accumulates the same taps in the same
+    // order, so the result does not depend on the choice (and the trial launches are idempotent).
+    const std::array<int, 4> shape{W, grows, win, nD};
+    std::vector<AswGeom> trial;
+    if (g_autotune && nD >= 1 && !getenv("SSAMD_ASW_GEOM") && !g_asw_geom_tuned.count(shape)) {
+        AswGeom tmp;
+        if (asw_search_geometry(tmp, W, grows, win, nD, &trial) != SSAMD_OK || trial.size() < 2) trial.clear();
+    }
+    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && g.nchunks == 1 && !consistent; };
+    bool need_keys = !is_direct(a.g) || alternate;  // the alternate mode merges its odd-row jobs through the left keys
+    for (const AswGeom &g : trial) need_keys = need_keys || !is_direct(g);
+    if (need_keys) {
         if ((rc = c.keyL.reserve(nout * 8))) return rc;
         HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
     }
@@ -409,27 +438,56 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
 
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
         a.prox = (const float *)c.prox.ptr;
-        a.keyL = direct ? nullptr : (u64 *)c.keyL.ptr; a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
-        a.disp = direct ? d_disp : nullptr;
+        a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
         a.costs = d_costs;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
         a.ystep = alternate ? 2 : 1;
-        const int grows = alternate ? (rows + 1) / 2 : rows;          // workgroup rows: every row, or the even ones
-        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, grows, a.g.nchunks), block(a.g.threads);
-        const bool chunked = a.g.JC < win;
-        auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
-                            : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
-        if (a.g.Rx == 4)
-            kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true, 4> : asw_aggregate_kernel<false, true, 4>)
-                           : (d_costs ? asw_aggregate_kernel<true, false, 4> : asw_aggregate_kernel<false, false, 4>);
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.g.lds_bytes));
-        {
-            Timed t(c, s, SSAMD_K_ASW_AGG);
-            hipLaunchKernelGGL(kern, grid, block, a.g.lds_bytes, s, a);
+        auto launch = [&](const AswGeom &g) -> int {
+            a.g = g;
+            a.keyL = is_direct(g) ? nullptr : (u64 *)c.keyL.ptr;
+            a.disp = is_direct(g) ? d_disp : nullptr;
+            const dim3 grid((W + g.Tx - 1) / g.Tx, grows, g.nchunks), block(g.threads);
+            const bool chunked = g.JC < win;
+            auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
+                                : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
+            if (g.Rx == 4)
+                kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true, 4> : asw_aggregate_kernel<false, true, 4>)
+                               : (d_costs ? asw_aggregate_kernel<true, false, 4> : asw_aggregate_kernel<false, false, 4>);
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes));
+            hipLaunchKernelGGL(kern, grid, block, g.lds_bytes, s, a);
             HIP_TRY(hipGetLastError());
+            return SSAMD_OK;
+        };
+        if (!trial.empty()) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            AswGeom fastest = a.g;
+            float best_ms = 3.0e38f;
+            for (const AswGeom &g : trial) {
+                if (launch(g) != SSAMD_OK) continue;                            // warm: code load, clocks
+                for (int rep = 0; rep < 3; ++rep) {                             // fastest of three timed launches
+                    float ms = 3.0e38f;
+                    if (hipEventRecord(e0, s) == hipSuccess && launch(g) == SSAMD_OK && hipEventRecord(e1, s) == hipSuccess &&
+                        hipEventSynchronize(e1) == hipSuccess)
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (ms < best_ms) { best_ms = ms; fastest = g; }
+                }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            g_asw_geom_cache[shape] = fastest;
+            g_asw_geom_tuned[shape] = true;
+            a.g = fastest;
+        }
+        {
+            const AswGeom final_geom = a.g;
+            Timed t(c, s, SSAMD_K_ASW_AGG);
+            if ((rc = launch(final_geom))) return rc;
         }
     }
+    const bool direct = is_direct(a.g);
     if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s))) return rc;
     if (alternate && rows > 1) {
         // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
@@ -644,6 +702,14 @@ const char *ssamd_kernel_name(int slot)
                                                "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
                                                "asw_alt_fill_kernel"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
+}
+
+int ssamd_autotune(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    const int before = g_autotune ? 1 : 0;
+    g_autotune = on != 0;
+    return before;
 }
 
 int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)

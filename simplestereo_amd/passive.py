@@ -42,7 +42,7 @@ import numpy as np
 
 from . import _native
 
-__all__ = ["StereoASW", "StereoGSW"]
+__all__ = ["StereoASW", "StereoGSW", "set_autotune"]
 
 _INT_MIN, _INT_MAX = -2 ** 31, 2 ** 31 - 1
 
@@ -101,6 +101,14 @@ def _device_index(device):
     if i < 0:
         raise ValueError("device must be None or a non-negative GPU index")
     return i
+
+
+def set_autotune(on=True):
+    """Extension: let the first ``StereoASW.compute`` call of every problem shape time its candidate launch
+    geometries on the GPU (about ten extra kernel launches, once) instead of trusting the cost model alone.
+    Maps are unaffected -- every geometry accumulates the same taps in the same order.  Returns the previous
+    setting.  Also enabled by the environment variable ``SSAMD_AUTOTUNE=1``."""
+    return bool(_native.lib().ssamd_autotune(1 if on else 0))
 
 
 def _raise_native(e):

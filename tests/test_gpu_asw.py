@@ -187,3 +187,32 @@ def test_asw_full_size_configs_3_and_5_known_shift_and_strip_invariance(H, W, ma
     h0, h1 = r0 - pad, r0 + rows + pad
     strip = m._compute_device(tL[h0:h1].contiguous(), tR[h0:h1].contiguous(), out_row0=r0 - h0, out_rows=rows)
     assert torch.equal(strip, d[r0:r0 + rows])
+
+
+def test_autotune_changes_the_geometry_never_the_map(ss, golden_inputs):
+    """with autotuning on, the first call of a shape times ~10 candidate geometries (8- and 4-column tiles, chunked
+    and unchunked, key path and direct path) on the call's buffers; the map must be the one of the model's choice"""
+    a, b = golden_inputs("synth_96x128")
+    cases = [dict(winSize=21, maxDisparity=39), dict(winSize=35, maxDisparity=16, consistent=True),
+             dict(winSize=9, maxDisparity=70, minDisparity=3), dict(winSize=15, maxDisparity=24, alternate=True)]
+    want = [ss.passive.StereoASW(**p).compute(a, b) for p in cases]
+    before = ss.passive.set_autotune(True)
+    try:
+        # other image sizes than `want` used, so these shapes have not been seen (tuned or cached) yet
+        a2, b2 = np.ascontiguousarray(a[:, :120]), np.ascontiguousarray(b[:, :120])
+        ref2 = [None] * len(cases)
+        got_first = [ss.passive.StereoASW(**p).compute(a2, b2) for p in cases]        # tuning calls
+        got_again = [ss.passive.StereoASW(**p).compute(a2, b2) for p in cases]        # tuned geometry from the cache
+    finally:
+        ss.passive.set_autotune(before)
+    from oracle import oracle
+    for p, g1, g2 in zip(cases, got_first, got_again):
+        assert np.array_equal(g1, g2)
+    os.environ["SSAMD_ASW_GEOM"] = "3,5,8"           # an unrelated forced geometry computes the same maps
+    try:
+        forced = [ss.passive.StereoASW(**p).compute(a2, b2) for p in cases]
+    finally:
+        del os.environ["SSAMD_ASW_GEOM"]
+    for g1, f in zip(got_first, forced):
+        assert np.array_equal(g1, f)
+    assert all(w.shape == (96, 128) for w in want)
