@@ -331,6 +331,17 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         }
         if (DG <= 2) break;
     }
+    // Measured exception to the cost model: with the 8-column tile and many disparity groups (DG >= 33, i.e. narrow
+    // x tiles under long weight rows) staging the tap columns in chunks of 16 is 1-1.5 % FASTER than whole rows --
+    // build and aggregation phases of different waves interleave (1080p/193: 46.9 -> 46.2 ms, 4K/257: 271.9 -> 269.2 ms,
+    // 1080p/129: 32.4 -> 32.0 ms) -- while for DG <= 25 it is 4-6 % slower, as the model says.
+    if (found && best.Rx == 8 && best.JC >= win && best.DG >= 33 && win > 16) {
+        AswGeom g;
+        if (asw_layout(g, win, best.XG, best.DG, 160 * 1024, 16, 8)) {
+            g.nchunks = best.nchunks;
+            best = g;
+        }
+    }
     if (shortlist && found) {
         std::vector<std::pair<double, AswGeom>> v;
         for (auto &kv : classes) v.push_back(kv.second);
