@@ -225,10 +225,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     // stage the pixels of image row r this tile touches into staging buffer `buf`
     // (coalesced 16 B loads; columns outside the image become zero records)
     auto stage_row = [&](int r, int buf) {
-        for (int k = tid; k < win; k += nthr) proxS[buf * win + k] = A.prox[(r - (y - p)) * win + k];
+        int tids = threadIdx.x;          // opaque copy: keeps the staging indices from being hoisted out of the
+        asm volatile("" : "+v"(tids));   // row loop and held (or spilled) across the aggregation
+        for (int k = tids; k < win; k += nthr) proxS[buf * win + k] = A.prox[(r - (y - p)) * win + k];
         const PixRec *const rowL = A.recL + (size_t)r * W;
         const PixRec *const rowR = A.recR + (size_t)r * W;
-        for (int k = tid; k < nL + nR; k += nthr) {
+        for (int k = tids; k < nL + nR; k += nthr) {
             const bool isL = k < nL;
             const int idx = isL ? k : k - nL;
             const int col = (isL ? segL_lo : segR_lo) + idx;
@@ -287,16 +289,14 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
         // a register tile contributes only if some (x,d) of it is a candidate the reference evaluates
         // (x - d >= 0, d <= maxDisparity, x < W); waves whose lanes are all outside (left image border,
         // padded disparities) skip the aggregation -- wave-uniform, decided once per window row
-        const int xg = tidm % g.XG, dg = tidm / g.XG;
-        const bool tile_live = tidm < g.XG * g.DG && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
-                               x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
-        const bool run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
-        const unsigned char *erow = eT + (RX * xg) * Se;
-        // swizzled dword slot of this thread's disparity group: depends on row / RX only, i.e. it
-        // changes once per RX tap columns (rows ul0 .. ul0+RX-1 share slot0)
-        int q = xg;
-        int slotA = (dg ^ (q & emask)) << 2;
-        AswRow ew[RX];
+        bool run;
+        {
+            const int xg = tidm % g.XG, dg = tidm / g.XG;
+            const bool tile_live = tidm < g.XG * g.DG && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
+                                   x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
+            run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
+        }
+        AswRow ew[RX];      // the only per-row state (besides the accumulators) that lives across the chunks' build phases
 
         for (int jc = 0; jc < win; jc += JC) {
             const int jend = min(win, jc + JC);
@@ -385,6 +385,17 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
 
             // ---- aggregation over the tap columns of this chunk
             if (run) {
+                // thread coordinates, e-row pointer and swizzle state are re-derived per chunk from an opaque thread
+                // id: nothing but the e window and the accumulators stays live across a weight-build phase
+                int tida = threadIdx.x;
+                asm volatile("" : "+v"(tida));
+                const int xg = tida % g.XG, dg = tida / g.XG;
+                // the next e row to load is ul0 + RX - 1 + jc (ul0 + 0 before the priming of the first chunk); the
+                // swizzled dword slot of the thread's disparity group depends on row / RX only, i.e. it changes
+                // once per RX tap columns
+                const unsigned char *erow = eT + (RX * xg + (jc == 0 ? 0 : RX - 1 + jc)) * Se;
+                int q = xg + jc / RX;
+                int slotA = (dg ^ (q & emask)) << 2;
                 if (jc == 0) {
 #pragma unroll
                     for (int n = 0; n < RX - 1; ++n) {
