@@ -27,7 +27,7 @@
 //                registers), then does 32 taps x {v_mul, 2 v_fma} + 4 x {cvt_ubyte, sub}.
 // HBM traffic is the pixel records only (16 B/pixel/image, re-read from L2 by
 // neighbouring tiles) plus 8-byte WTA keys; everything else lives in LDS/VGPRs.
-// Measured (1080p, D 0..192, win 35): 47.0 ms, 3.5e10 VALU wave-instructions at ~83 % of the
+// Measured (1080p, D 0..192, win 35): 45.6-46.4 ms, 3.5e10 VALU wave-instructions at ~83 % of the
 // plain fp32 issue rate, no scratch, LDS ~50 % busy (profiles/).
 #pragma once
 #include "common.hip.h"
