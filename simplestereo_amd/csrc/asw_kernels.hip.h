@@ -49,6 +49,9 @@ struct AswGeom {
     int SL, hL, hR;              // wL row stride and the half offsets of the parity-split wL / wR rows
     int wseg, wlen;              // weight build: tap columns (of a chunk) split in wseg segments of wlen
     int JC;                      // tap columns staged per chunk (multiple of ASW_RX); >= win: one chunk
+    int e2;                      // 1: two e tiles (rows alternate): no barrier between the last chunk of a window row and
+                                 //    the e / weight build of the next one (chunked form with >= 2 chunks only)
+    int e_bytes;                 // size of one e tile
     int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
 };
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     const AswGeom &g = A.g;
     float *const wL = reinterpret_cast<float *>(smem + g.off_wL);
     float *const wR = reinterpret_cast<float *>(smem + g.off_wR);
-    unsigned char *const eT = reinterpret_cast<unsigned char *>(smem + g.off_e);
+    unsigned char *const eT0 = reinterpret_cast<unsigned char *>(smem + g.off_e);
     float4 *const labL = reinterpret_cast<float4 *>(smem + g.off_labL);
     float4 *const labR = reinterpret_cast<float4 *>(smem + g.off_labR);
     uint32_t *const bgrL = reinterpret_cast<uint32_t *>(smem + g.off_bgrL);
@@ -259,7 +262,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
         float4 *const labLc = labL + (i & 1) * nL, *const labRc = labR + (i & 1) * nR;
         uint32_t *const bgrLc = bgrL + (i & 1) * nL, *const bgrRc = bgrR + (i & 1) * nR;
         if (i == i_lo) stage_row(r, i & 1);
-        __syncthreads();   // staged pixels visible; every thread is done with main(i-1)
+        // staged pixels visible; every thread is done with main(i-1).  With two e tiles the barrier is only needed
+        // for the first row: the pixels of later rows were staged before an earlier chunk barrier of the previous row,
+        // this row's e tile and first weight chunk go to the buffers the previous row's last chunk does not read,
+        // and stragglers of that chunk are waited for at this row's first chunk barrier.
+        if (!(CHUNKED && g.e2) || i == i_lo) __syncthreads();
+        unsigned char *const eT = eT0 + ((CHUNKED && g.e2) ? (i & 1) * g.e_bytes : 0);
 
         // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|) (_passive.cpp:77-79);
         //      pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels.  Task = (tap column ul,

@@ -176,7 +176,7 @@ int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ ASW geometry
-bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20, int Rx = ASW_RX)
+bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int Rx, bool e2, bool odd_pitch = false)
 {
     g.Rx = Rx;
     g.JC = JC >= win ? win : JC;                 // tap columns staged per chunk; win = the whole row at once
@@ -201,6 +201,10 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 <<
     if (P < DG) P = round_up(DG, 32);
     g.Se = 4 * P;
     g.emask = std::min(P, 32) - 1;
+    if (odd_pitch) {                            // plain rows with an odd dword pitch instead of the XOR swizzle
+        g.Se = 4 * (DG | 1);
+        g.emask = 0;
+    }
     // weight build balance: (centres x segments) tasks over the workgroup's threads
     {
         const int ncen = g.Tx + g.nRc;
@@ -215,7 +219,9 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 <<
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
     g.off_wL = take((size_t)wrows * g.SL * 4);
     g.off_wR = take((size_t)wrows * g.SR * 4);
-    g.off_e = take((size_t)g.nL * g.Se);
+    g.e_bytes = (int)(((size_t)g.nL * g.Se + 15) & ~(size_t)15);
+    g.e2 = (e2 && g.JC < win && (win + g.JC - 1) / g.JC >= 2) ? 1 : 0;
+    g.off_e = take((size_t)g.e_bytes * (g.e2 ? 2 : 1));
     g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
     g.off_labR = take((size_t)g.nR * 16 * 2);
     g.off_bgrL = take((size_t)g.nL * 4 * 2);
@@ -226,6 +232,51 @@ bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 <<
     g.off_prox = take((size_t)win * 4 * 2);      // one window row of proximity weights, double-buffered
     g.lds_bytes = (int)off;
     return off <= limit;
+}
+
+// Chunked geometries first try two e tiles (no row-start barrier, asw_kernels.hip.h); when that does not fit the
+// LDS budget they fall back to one.
+bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20, int Rx = ASW_RX, bool odd_pitch = false)
+{
+    if (!getenv("SSAMD_ASW_NO_E2") && asw_layout_e(g, win, XG, DG, limit, JC, Rx, true, odd_pitch) && g.e2) return true;
+    return asw_layout_e(g, win, XG, DG, limit, JC, Rx, false, odd_pitch);
+}
+
+// Average number of LDS passes of the aggregation loop's e-row read (one dword per lane; a wave is served in two
+// halves of 32 lanes, a pass per distinct address that shares a bank) for an e layout: lanes = consecutive thread
+// ids, thread (xg, dg) reads dword dg (XOR-swizzled with row / Rx & emask) of row Rx*xg + n.
+double asw_e_read_passes(const AswGeom &g)
+{
+    const int P = g.Se / 4, T = g.XG * g.DG;
+    long long tot = 0, cnt = 0;
+    for (int n = 0; n < g.Rx; ++n)
+        for (int base = 0; base < T; base += 32) {
+            int hits[64] = {0}, worst = 0;
+            for (int l = 0; l < 32 && base + l < T; ++l) {
+                const int tid = base + l, xg = tid % g.XG, dg = tid / g.XG, ul = g.Rx * xg + n;
+                worst = std::max(worst, ++hits[(ul * P + (dg ^ ((ul / g.Rx) & g.emask))) & 63]);
+            }
+            tot += worst; ++cnt;
+        }
+    return cnt ? (double)tot / cnt : 1.0;
+}
+
+// The e-tile scheme is decided for the chosen tile only (the search prices LDS with the swizzled form): rows with an
+// odd dword pitch are smaller (DG|1 instead of a power of two / multiple of 32 dwords) and often conflict less for
+// narrow thread grids; the XOR swizzle wins for wide ones.  Take the odd pitch when it makes room for a second e
+// tile, or when it does not read slower.
+void asw_pick_e_scheme(AswGeom &g, int win)
+{
+    if (getenv("SSAMD_ASW_XOR_ONLY")) return;
+    AswGeom alt;
+    if (!asw_layout(alt, win, g.XG, g.DG, 160 * 1024, g.JC >= win ? (1 << 20) : g.JC, g.Rx, true)) return;
+    // two e tiles (one barrier less per window row: 1080p/193 45.96 -> 44.7 ms) outweigh a few bank conflicts of a
+    // one-dword read; among equals the layout with fewer passes wins
+    const bool take = alt.e2 != g.e2 ? alt.e2 > g.e2 : asw_e_read_passes(alt) <= asw_e_read_passes(g) + 1e-9;
+    if (take) {
+        alt.nchunks = g.nchunks;
+        g = alt;
+    }
 }
 
 // Pick the workgroup tile (XG column groups x DG disparity groups, nchunks disparity chunks)
@@ -273,6 +324,7 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             if (JCe <= 0 || JCe % Rx) JCe = 1 << 20;
             if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe, Rx)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
+            asw_pick_e_scheme(best, win);
             return SSAMD_OK;
         }
     }
@@ -342,12 +394,16 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             best = g;
         }
     }
+    if (found) asw_pick_e_scheme(best, win);
     if (shortlist && found) {
         std::vector<std::pair<double, AswGeom>> v;
         for (auto &kv : classes) v.push_back(kv.second);
         std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         shortlist->clear();
-        for (size_t i = 0; i < v.size() && i < 10 && v[i].first > 0.6 * best_score; ++i) shortlist->push_back(v[i].second);
+        for (size_t i = 0; i < v.size() && i < 10 && v[i].first > 0.6 * best_score; ++i) {
+            asw_pick_e_scheme(v[i].second, win);
+            shortlist->push_back(v[i].second);
+        }
     }
     return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no ASW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
 }
