@@ -154,9 +154,16 @@ def test_asw_forced_geometries_and_chunked_staging_agree(geom, ss, golden_inputs
     os.environ["SSAMD_ASW_GEOM"] = geom
     try:
         got = m.compute(a, b)
+        # the same tile without the second e tile (row-start barrier kept) and with the XOR-swizzled e rows only
+        os.environ["SSAMD_ASW_NO_E2"] = "1"
+        got_one_e = m.compute(a, b)
+        os.environ["SSAMD_ASW_XOR_ONLY"] = "1"
+        got_xor = m.compute(a, b)
     finally:
-        del os.environ["SSAMD_ASW_GEOM"]
+        for k in ("SSAMD_ASW_GEOM", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY"):
+            os.environ.pop(k, None)
     assert np.array_equal(got, want)
+    assert np.array_equal(got_one_e, want) and np.array_equal(got_xor, want)
 
 
 @pytest.mark.parametrize("H,W,maxd,shift", [(1080, 1920, 192, 150), (2160, 4096, 256, 233)])
