@@ -161,8 +161,8 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     const GswGeom &g = A.g;
     float *const wS = reinterpret_cast<float *>(smem + g.off_w);          // [TY][win][Tx]
     float *const eT = reinterpret_cast<float *>(smem + g.off_e);          // [nL][Se]
-    GswPix *const refS = reinterpret_cast<GswPix *>(smem + g.off_ref);    // [nL]
-    GswPix *const tgtS = reinterpret_cast<GswPix *>(smem + g.off_tgt);    // [nT]
+    GswPix *const refS0 = reinterpret_cast<GswPix *>(smem + g.off_ref);   // [2][nL4]: image rows alternate
+    GswPix *const tgtS0 = reinterpret_cast<GswPix *>(smem + g.off_tgt);   // [2][nT4]
     u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [TY][Tx]
 
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -196,17 +196,24 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
 
     // image rows in ascending order: every output row sees its window rows in the reference's raster order
     const int r_lo = max(0, y0 - p), r_hi = min(H - 1, y0 + ny - 1 + p);
-    for (int r = r_lo; r <= r_hi; ++r) {
-        __syncthreads();                    // previous image row fully consumed
-        for (int k = tid; k < nL4 + nT4; k += nthr) {   // staged pixels: norm computed once per pixel,
-            const bool isRef = k < nL4;                  // not once per (pixel, disparity) element
+    // pixels of image row rr into staging buffer `buf` (norm computed once per pixel, not once per (pixel,
+    // disparity) element).  Rows are staged one ahead: the global latency sits under the previous row's taps and
+    // the barrier that ends those taps also publishes the pixels.
+    auto stage_row = [&](int rr, int buf) {
+        GswPix *const rS = refS0 + buf * nL4, *const tS = tgtS0 + buf * nT4;
+        for (int k = tid; k < nL4 + nT4; k += nthr) {
+            const bool isRef = k < nL4;
             const int idx = isRef ? k : k - nL4;
             const int col = (isRef ? seg_lo : tgt_lo) + idx;
             GswPix v = gsw_pix(0u, 0.f);
-            if ((unsigned)col < (unsigned)W) v = gsw_pix((isRef ? A.ref : A.tgt)[(size_t)r * W + col], 1.f);
-            (isRef ? refS : tgtS)[idx] = v;
+            if ((unsigned)col < (unsigned)W) v = gsw_pix((isRef ? A.ref : A.tgt)[(size_t)rr * W + col], 1.f);
+            (isRef ? rS : tS)[idx] = v;
         }
-        __syncthreads();
+    };
+    stage_row(r_lo, r_lo & 1);
+    for (int r = r_lo; r <= r_hi; ++r) {
+        __syncthreads();                    // previous image row fully consumed; this row's pixels staged
+        const GswPix *const refS = refS0 + (r & 1) * nL4, *const tgtS = tgtS0 + (r & 1) * nT4;
 
         // ---- support weights of this image row for the tile's reference pixels, per output row:
         //      image row r is window row i = r - y + pad of output row y.  A thread keeps one reference
@@ -280,6 +287,7 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
             }
         }
         __syncthreads();
+        if (r < r_hi) stage_row(r + 1, (r + 1) & 1);       // prefetch: its global latency sits under the taps below
 
         if (active) {
             if constexpr (TY == 1) {

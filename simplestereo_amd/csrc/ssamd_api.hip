@@ -604,8 +604,8 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
     g.off_w = take((size_t)Ty * win * g.Tx * 4);
     const int nL4 = round_up(g.nL, 4);                 // the e tasks cover 4 columns
     g.off_e = take((size_t)nL4 * g.Se * 4);
-    g.off_ref = take((size_t)nL4 * 16);
-    g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16);
+    g.off_ref = take((size_t)nL4 * 16 * 2);            // pixel staging is double-buffered (prefetch of the next image row)
+    g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16 * 2);
     g.off_best = take((size_t)Ty * g.Tx * 8);
     g.lds_bytes = (int)off;
     return off <= limit;
