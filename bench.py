@@ -267,6 +267,19 @@ def main():
                      "frac": (VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) / VALU_PEAK_LANEOPS) if k_ms > 0 else None},
             "kernels_ms_per_step": {_native.lib().ssamd_kernel_name(i).decode(): ms[i] / args.steps for i in range(_native.K_COUNT) if launches[i]},
         }
+        # VALU issue rate: instruction count per launch from the committed rocprofv3 PMC pass (like `traffic`),
+        # against the plain-fp32 issue rate measured on this chip by tools/ubench_valu.hip
+        vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % args.config)
+        if world == 1 and os.path.exists(vpath) and k_ms > 0:
+            try:
+                vj = json.load(open(vpath))
+                rate = vj["SQ_INSTS_VALU_per_launch"] / (k_ms * 1e-3) / 1024 / 1e9          # 256 CUs x 4 SIMDs
+                line["valu"]["issue"] = {"wave_instructions_per_launch": vj["SQ_INSTS_VALU_per_launch"],
+                                         "achieved_G_wave_instr_per_s_per_simd": rate,
+                                         "plain_fp32_peak_G_wave_instr_per_s_per_simd": vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"],
+                                         "frac": rate / vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"]}
+            except Exception:      # noqa: BLE001
+                pass
         if world == 1 and not args.consistent and args.with_alternate:
             # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
             alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
