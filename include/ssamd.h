@@ -153,11 +153,13 @@ int ssamd_profile_reset(void);
 int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);
 const char *ssamd_kernel_name(int slot);
 
-/* Autotuning of the ASW launch geometry (off by default; also switched on by the environment variable
- * SSAMD_AUTOTUNE=1).  When on, the first ssamd_asw* call for a problem shape (width, rows, winSize, number of
- * disparities) times the best tile of every class of candidates on the call's own buffers -- about ten extra
- * launches, once -- and later calls reuse the fastest.  The disparity maps do not depend on the geometry.
- * Returns the previous setting. */
+/* Autotuning of the ASW launch geometry.  When it applies, the first ssamd_asw* call for a problem shape (width,
+ * rows, winSize, number of disparities) times the best tile of every class of candidates on the call's own
+ * buffers -- up to ten candidates, five launches each in round-robin order, once -- and later calls reuse the
+ * fastest.  The disparity maps do not depend on the geometry.  on = 1: always; 0: never; -1 (the default, also
+ * SSAMD_AUTOTUNE=-1): only for calls of at most 3e10 window taps (3-4 ms of kernel time: VGA / 720p frames,
+ * small disparity ranges), where the trial launches cost at most ~0.2 s once and the cost model is least reliable.  The environment
+ * variable SSAMD_AUTOTUNE=1 / 0 / -1 sets the initial mode.  Returns the previous mode. */
 int ssamd_autotune(int on);
 
 /* Launch geometry chosen for an ASW problem (for DESIGN.md / bench reporting).

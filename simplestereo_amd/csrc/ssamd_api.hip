@@ -295,7 +295,10 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
 // a video stream asks the same question every frame.  (Callers hold g_mutex.)
 std::map<std::array<int, 4>, AswGeom> g_asw_geom_cache;
 std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached geometry was picked by measurement
-bool g_autotune = getenv("SSAMD_AUTOTUNE") != nullptr && atoi(getenv("SSAMD_AUTOTUNE")) != 0;
+// autotuning mode: 1 always, 0 never, -1 (default) only for small problems, where the ~50 trial launches cost
+// at most about 0.2 s once and where the cost model is least reliable
+int g_autotune = getenv("SSAMD_AUTOTUNE") ? (atoi(getenv("SSAMD_AUTOTUNE")) > 0 ? 1 : (atoi(getenv("SSAMD_AUTOTUNE")) < 0 ? -1 : 0)) : -1;
+constexpr double ASW_AUTOTUNE_SMALL_TAPS = 3.0e10;      // window taps per call (about 3-4 ms of kernel time)
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
@@ -479,7 +482,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     // order, so the result does not depend on the choice (and the trial launches are idempotent).
     const std::array<int, 4> shape{W, grows, win, nD};
     std::vector<AswGeom> trial;
-    if (g_autotune && nD >= 1 && !getenv("SSAMD_ASW_GEOM") && !g_asw_geom_tuned.count(shape)) {
+    const double call_taps = (double)W * grows * nD * win * win;
+    const bool tune_now = g_autotune > 0 || (g_autotune < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS);
+    if (tune_now && nD >= 1 && !getenv("SSAMD_ASW_GEOM") && !g_asw_geom_tuned.count(shape)) {
         AswGeom tmp;
         if (asw_search_geometry(tmp, W, grows, win, nD, &trial) != SSAMD_OK || trial.size() < 2) trial.clear();
     }
@@ -530,18 +535,24 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             hipEvent_t e0 = nullptr, e1 = nullptr;
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
+            // round-robin over the candidates, several rounds, fastest launch of each: clocks ramp up during the
+            // first launches after an idle period, so timing the candidates one after the other would favour the
+            // late ones
+            std::vector<float> cand_ms(trial.size(), 3.0e38f);
+            for (const AswGeom &g : trial) (void)launch(g);                  // code load, clocks
+            for (int round = 0; round < 4; ++round)
+                for (size_t ci = 0; ci < trial.size(); ++ci) {
+                    float ms = 3.0e38f;
+                    if (hipEventRecord(e0, s) == hipSuccess && launch(trial[ci]) == SSAMD_OK &&
+                        hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (round > 0) cand_ms[ci] = std::min(cand_ms[ci], ms);  // round 0 is warm-up
+                }
             AswGeom fastest = a.g;
             float best_ms = 3.0e38f;
-            for (const AswGeom &g : trial) {
-                if (launch(g) != SSAMD_OK) continue;                            // warm: code load, clocks
-                for (int rep = 0; rep < 3; ++rep) {                             // fastest of three timed launches
-                    float ms = 3.0e38f;
-                    if (hipEventRecord(e0, s) == hipSuccess && launch(g) == SSAMD_OK && hipEventRecord(e1, s) == hipSuccess &&
-                        hipEventSynchronize(e1) == hipSuccess)
-                        (void)hipEventElapsedTime(&ms, e0, e1);
-                    if (ms < best_ms) { best_ms = ms; fastest = g; }
-                }
-            }
+            for (size_t ci = 0; ci < trial.size(); ++ci)
+                // the model's own choice (first) keeps the job unless another candidate is clearly faster
+                if (cand_ms[ci] < best_ms * (ci == 0 ? 1.0f : 0.985f)) { best_ms = cand_ms[ci]; fastest = trial[ci]; }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             g_asw_geom_cache[shape] = fastest;
@@ -774,8 +785,8 @@ const char *ssamd_kernel_name(int slot)
 int ssamd_autotune(int on)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
-    const int before = g_autotune ? 1 : 0;
-    g_autotune = on != 0;
+    const int before = g_autotune;
+    g_autotune = on > 0 ? 1 : (on < 0 ? -1 : 0);
     return before;
 }
 
