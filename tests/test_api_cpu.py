@@ -140,3 +140,16 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
                 assert "liboracle" not in src and "oracle_passive" not in src, f
+
+
+def test_autotune_mode_round_trip(ss):
+    """mode switch of the launch-geometry autotuner (pure host state: works without a GPU);
+    default = None = 'small problems only'"""
+    first = ss.passive.set_autotune(True)
+    try:
+        assert first in (None, True, False)
+        assert ss.passive.set_autotune(False) is True
+        assert ss.passive.set_autotune(None) is False
+        assert ss.passive.set_autotune(True) is None
+    finally:
+        ss.passive.set_autotune(first)
