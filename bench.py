@@ -14,15 +14,25 @@ isend/irecv), runs the kernels on its strip and all-gathers the int16 strips.
 
 Rank 0 prints ONE JSON line.  metric = disparity MPixels/s = H*W*nD / t / 1e6
 (nD = maxDisparity - minDisparity + 1), whole job.  Extra objects:
-  roofline      the dominant kernel (asw_aggregate_kernel) against the HBM roofline the
-                north_star names: algorithmic bytes (34 B/pixel: two 16 B pixel records
-                read + one int16 written) / measured kernel time, peak 8 TB/s.  The
-                kernel is VALU-bound by ~3 orders of magnitude, so the
-                binding figure is in "valu": lane-ops/tap x taps / time vs the fp32
-                vector peak.
+  roofline      the dominant kernel (asw_aggregate_kernel) against the bound that BINDS it:
+                fp32 VALU issue.  achieved = exact window taps of the launch x 3 lane-ops per
+                tap (the irreducible v_mul_f32 w = wL*wR, v_fma_f32 N += w*e, v_fma_f32
+                S' += w*(40-e)) / kernel time measured live with HIP events on the launch
+                stream; peak = 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s (157.3 TFLOP/s
+                fp32).  "hbm" inside it is the roofline north_star names (34 B/pixel algorithmic
+                bytes vs 8 TB/s): three orders of magnitude away from binding.
+                `traffic` and `issue` are REPLAYED from committed rocprofv3 PMC passes of the
+                same command (their "source" key says which file); everything else is live.
+  others        the other BASELINE configurations, timed in the same run after the timed
+                region (config 2, config 5 on one GPU, config 3 consistent=True, the class
+                default D 0..16, and GSW config 4), each with its own kernel time and VALU fraction.
   cpu_baseline  the reference's own C++ extension (oracle/_ref, kind "reference") or
                 the plain-C port (oracle/, kind "port", literal mode) timed on this
-                box's host cores on a bounded strip of the same frame.
+                box's host cores on a bounded strip of the same frame with >= 2 rows per
+                host thread (the reference hands out one row per job, _passive.cpp:372-374),
+                so that every thread is busy; plus "hoisted": the plain-C port with the same
+                algebraic shortcut as the GPU (right weights evaluated once per pixel, not once
+                per candidate), kind "port-hoisted", timed the same way.
   bad1_vs_cpu_ref  the second half of BASELINE's metric: % of pixels of that strip whose GPU
                 disparity differs from the CPU reference's by more than 1 level.
 """
@@ -42,12 +52,25 @@ CONFIGS = {
     "c3_1080p_d192_w35": (1080, 1920, 192, 0, 35),
     "c2_480p_d64_w35": (480, 640, 64, 0, 35),
     "c5_4k_d256_w35": (2160, 4096, 256, 0, 35),
+    "default_1080p_d16_w35": (1080, 1920, 16, 0, 35),      # StereoASW() class defaults (passive.py:59) on a 1080p frame
+}
+GSW_CONFIGS = {
+    # BASELINE config 4: StereoGSW class defaults (winSize 11, gamma 10, fMax 120, iterations 3) at 1080p / D 0..192
+    "c4_gsw_1080p_d192_w11": (1080, 1920, 192, 0, 11),
 }
 GAMMA_C, GAMMA_P = 5.0, 17.5
+GSW_GAMMA, GSW_FMAX, GSW_ITER = 10, 120.0, 3
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (=157.3 TFLOP/s fp32 FMA)
 ALGO_BYTES_PER_PIXEL = 34        # read 2 x 16 B records, write 2 B
-VALU_OPS_PER_TAP = 4             # nominal lane-ops per window tap: mul + 2 fma (N, S') + amortised cvt/sub
+GSW_ALGO_BYTES_PER_PIXEL = 10    # read 2 x 4 B packed pixels, write 2 B
+# irreducible lane-ops per window tap of the ASW aggregation: v_mul_f32 (w = wL*wR), v_fma_f32 (N += w*e),
+# v_fma_f32 (S' += w*(40-e)); unpacking e (v_cvt_f32_ubyteN + v_sub per 8 taps) and addressing come on top
+VALU_OPS_PER_TAP = 3
+VALU_TAP_INSTRUCTIONS = ["v_mul_f32 w=wL*wR", "v_fma_f32 N+=w*e", "v_fma_f32 S'+=w*(40-e)"]
+# GSW: bit-exactness with the reference's fp32 loop dictates an UNFUSED multiply and add per tap, both passes
+GSW_OPS_PER_TAP = 2
+GSW_TAP_INSTRUCTIONS = ["v_mul_f32 t=w*e", "v_add_f32 cost+=t"]
 
 
 def count_taps(H, W, win, maxD, minD, row0=0, rows=None):
@@ -66,8 +89,12 @@ def count_taps(H, W, win, maxD, minD, row0=0, rows=None):
     return int(vrows.sum()) * int(cols.sum())
 
 
-def cpu_baseline(cfg, seed, budget_s=20.0):
-    """Time the reference (or the port) on a bounded strip of the same frame, on the host cores."""
+def cpu_baseline(cfg, seed, rows_per_thread=2, timeout_s=900):
+    """Time the reference (and the hoisted plain-C port) on a bounded strip of the same frame, on the host cores.
+
+    The reference hands out ONE image row per job to hardware_concurrency() threads (_passive.cpp:352-355, 372-396),
+    so a strip keeps every host thread busy only if it has at least as many rows as there are threads: the strip is
+    the centre `rows_per_thread x threads` rows of the frame (whole frame if that is more than it has)."""
     H, W, maxD, minD, win = cfg
     code = r"""
 import sys, time, json, os
@@ -76,63 +103,172 @@ import numpy as np
 from oracle import oracle
 from simplestereo_amd.synth import make_pair
 H, W, maxD, minD, win, rows, seed = %d, %d, %d, %d, %d, int(sys.argv[1]), %d
+mode = sys.argv[3]
 L, R, _ = make_pair(H, W, maxD, seed)
 r0 = (H - rows) // 2
 a, b = np.ascontiguousarray(L[r0:r0 + rows]), np.ascontiguousarray(R[r0:r0 + rows])
-ref = oracle.ref_module()
+ref = oracle.ref_module() if mode == "reference" else None
+oracle.asw(a[:2, :64], b[:2, :64], 5, 4, 0, %r, %r)       # load the library outside the timed region
 t = time.time()
-if ref is not None:
+if mode == "hoisted":
+    d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=True); kind = "port-hoisted"
+elif ref is not None:
     d = ref.computeASW(a, b, win, maxD, minD, %r, %r, False); kind = "reference"
 else:
     d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=False); kind = "port"
-if len(sys.argv) > 2:
-    np.save(sys.argv[2], d)
-print(json.dumps({"t": time.time() - t, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}))
-""" % (ROOT, H, W, maxD, minD, win, seed, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P)
+dt = time.time() - t
+np.save(sys.argv[2], d)
+print(json.dumps({"t": dt, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}))
+""" % (ROOT, H, W, maxD, minD, win, seed, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P)
 
     import tempfile
     dump = os.path.join(tempfile.gettempdir(), "ssamd_cpu_ref_%d.npy" % os.getpid())
+    dump_h = os.path.join(tempfile.gettempdir(), "ssamd_cpu_hoist_%d.npy" % os.getpid())
 
-    def run(rows, timeout):
-        out = subprocess.run([sys.executable, "-c", code, str(rows), dump], capture_output=True, text=True, timeout=timeout)
+    def run(rows, mode, path):
+        out = subprocess.run([sys.executable, "-c", code, str(rows), path, mode], capture_output=True, text=True,
+                             timeout=timeout_s)      # the reference's queue has an empty()/pop() race: bounded wait
         res = json.loads(out.stdout.strip().splitlines()[-1])
         res["rows"] = rows
         return res
 
     cores = os.cpu_count() or 1
+    rows = min(H, max(rows_per_thread * cores, 8))
+    full = count_taps(H, W, win, maxD, minD)
+    taps = count_taps(rows, W, win, maxD, minD)          # the strip is matched as a stand-alone sub-image
+    nD = maxD - minD + 1
+
+    def entry(res):
+        t_full = res["t"] * full / taps                  # per-tap cost is uniform
+        return {"value": H * W * nD / t_full / 1e6, "unit": "MPixels*disp/s", "cores": res["cores"], "kind": res["kind"],
+                "strip_row0": res["r0"], "strip_rows": rows, "threads_busy": min(rows, res["cores"]),
+                "rows_per_thread": rows / float(res["cores"]), "wall_s": res["t"],
+                "sample": "%dx%d centre strip (%d rows = %.1f row jobs per host thread) of the same frame, %.3g of the "
+                          "frame's %.4g window taps, %.1f s wall on %d host threads; scaled to the full frame by tap count" %
+                          (W, rows, rows, rows / float(res["cores"]), taps / full, float(full), res["t"], res["cores"])}
     try:
-        probe_rows = 2
-        probe = run(probe_rows, 300)                     # also warms the page cache / libm
-        taps_probe = count_taps(probe_rows, W, win, maxD, minD)
-        rate = taps_probe / max(probe["t"], 1e-6)         # taps/s (very rough: tiny job)
-        # choose rows so the timed run lasts ~budget_s; a strip of `rows` rows has clipped windows
-        rows = probe_rows
-        for cand in (4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256):
-            if cand > H:
-                break
-            if count_taps(cand, W, win, maxD, minD) / rate <= budget_s:
-                rows = cand
-        res = run(rows, 600)                              # reference has an empty()/pop() race: bounded wait
-        taps = count_taps(rows, W, win, maxD, minD)
-        if res["t"] < budget_s / 3:                       # the 2-row probe underestimates the rate: rescale once
-            rate = taps / max(res["t"], 1e-6)
-            bigger = rows
-            for cand in (8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512):
-                if cand <= H and cand > rows and count_taps(cand, W, win, maxD, minD) / rate <= budget_s:
-                    bigger = cand
-            if bigger > rows:
-                rows = bigger
-                res = run(rows, 600)
-                taps = count_taps(rows, W, win, maxD, minD)
-        full = count_taps(H, W, win, maxD, minD)
-        t_full = res["t"] * full / taps                   # per-tap cost is uniform
-        return {"value": H * W * (maxD - minD + 1) / t_full / 1e6, "unit": "MPixels*disp/s", "cores": res["cores"],
-                "kind": res["kind"], "strip_row0": res["r0"], "strip_rows": rows, "map_file": dump,
-                "sample": "%dx%d centre strip (%d rows) of the same frame, %.3g of the frame's %.4g window taps, "
-                          "%.1f s wall on %d host threads; scaled to the full frame by tap count" %
-                          (W, rows, rows, taps / full, float(full), res["t"], res["cores"])}
+        cb = entry(run(rows, "reference", dump))
+        cb["map_file"] = dump
     except Exception as e:      # noqa: BLE001  -- the baseline must never sink the bench line
         return {"value": None, "unit": "MPixels*disp/s", "cores": cores, "kind": "unavailable", "sample": repr(e)[:200]}
+    try:
+        # the second comparison BASELINE.md section 3 asks for: a CPU mode with the SAME algebraic shortcut as the GPU
+        # kernels (the other image's support weights evaluated once per pixel and window row instead of once per
+        # candidate; bit-identical maps, tests/test_oracle_golden.py)
+        hb = entry(run(rows, "hoisted", dump_h))
+        import numpy as np
+        hb["map_equals_reference_map"] = bool(np.array_equal(np.load(dump), np.load(dump_h)))
+        os.remove(dump_h)
+        cb["hoisted"] = hb
+    except Exception as e:      # noqa: BLE001
+        cb["hoisted"] = {"value": None, "kind": "unavailable", "sample": repr(e)[:200]}
+    return cb
+
+
+def replayed_counters(config_name, k_ms):
+    """HBM traffic and VALU instruction counts of the dominant kernel: NOT measured in this run (rocprofv3 PMC passes
+    cannot run inside the timed command) but replayed from the committed passes of the same command; tagged as such."""
+    traffic = issue = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % config_name)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = next(v.get("hbm_bytes_per_launch") for k, v in tj.items() if "asw_aggregate" in k)
+        except Exception:      # noqa: BLE001
+            traffic = None
+    vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % config_name)
+    if os.path.exists(vpath) and k_ms > 0:
+        try:
+            vj = json.load(open(vpath))
+            rate = vj["SQ_INSTS_VALU_per_launch"] / (k_ms * 1e-3) / 1024 / 1e9          # 256 CUs x 4 SIMDs
+            issue = {"wave_instructions_per_launch": vj["SQ_INSTS_VALU_per_launch"],
+                     "achieved_G_wave_instr_per_s_per_simd": rate,
+                     "plain_fp32_peak_G_wave_instr_per_s_per_simd": vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"],
+                     "frac": rate / vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"],
+                     "source": "profiles/valu_%s.json (builder rocprofv3 --pmc SQ_INSTS_VALU run of this command, kernel %s); "
+                               "the kernel time it is divided by is this run's" % (config_name, vj.get("kernel", "?"))}
+        except Exception:      # noqa: BLE001
+            issue = None
+    return traffic, ("profiles/traffic_%s.json (builder rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command, "
+                     "2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction)" % config_name) if traffic else None, issue
+
+
+def time_matcher(matcher, tL, tR, slot, steps=3, warmup=1):
+    """(wall ms per step, kernel ms per launch of profile slot `slot`) of matcher.compute on resident tensors"""
+    import torch
+    from simplestereo_amd import _native
+    lib = _native.lib()
+    for _ in range(warmup):
+        out = matcher.compute(tL, tR)
+    torch.cuda.synchronize()
+    lib.ssamd_profile_enable(1)
+    lib.ssamd_profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = matcher.compute(tL, tR)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    ms, launches = _native.profile_read()
+    lib.ssamd_profile_enable(0)
+    k_ms = ms[slot] / max(1, launches[slot]) * (launches[slot] / float(steps)) if launches[slot] else None
+    return wall, k_ms, int(out.to(torch.int64).sum().item())
+
+
+def others(dev, seed):
+    """The BASELINE configurations that are not the bench line, timed in the same run (1 GPU, resident inputs)."""
+    import numpy as np
+    import torch
+    import simplestereo_amd as ss
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    res = {}
+    cache = {}
+
+    def pair(H, W, maxD):
+        if (H, W, maxD) not in cache:
+            L, R, _ = make_pair(H, W, maxD, seed)
+            cache[(H, W, maxD)] = (torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev))
+        return cache[(H, W, maxD)]
+
+    jobs = [("c3_1080p_d192_w35_consistent", "c3_1080p_d192_w35", True), ("c2_480p_d64_w35", "c2_480p_d64_w35", False),
+            ("default_1080p_d16_w35", "default_1080p_d16_w35", False), ("c5_4k_d256_w35_1gpu", "c5_4k_d256_w35", False)]
+    for name, cfgname, consistent in jobs:
+        try:
+            H, W, maxD, minD, win = CONFIGS[cfgname]
+            tL, tR = pair(H, W, maxD)
+            m = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
+                                     consistent=consistent)
+            wall, k_ms, checksum = time_matcher(m, tL, tR, _native.K_ASW_AGG)
+            taps = count_taps(H, W, win, maxD, minD)
+            nD = maxD - minD + 1
+            res[name] = {"matcher": "StereoASW", "H": H, "W": W, "maxDisparity": maxD, "minDisparity": minD, "winSize": win,
+                         "consistent": consistent, "ms_per_step": wall, "value": H * W * nD / (wall * 1e-3) / 1e6,
+                         "unit": "MPixels*disp/s", "kernel_ms": k_ms, "taps": taps, "checksum": checksum,
+                         "valu_frac": VALU_OPS_PER_TAP * taps / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None}
+        except Exception as e:      # noqa: BLE001
+            res[name] = {"error": repr(e)[:200]}
+    for name, (H, W, maxD, minD, win) in GSW_CONFIGS.items():
+        try:
+            tL, tR = pair(H, W, maxD)
+            m = ss.passive.StereoGSW(winSize=win, maxDisparity=maxD, minDisparity=minD, gamma=GSW_GAMMA, fMax=GSW_FMAX,
+                                     iterations=GSW_ITER)
+            wall, k_ms, checksum = time_matcher(m, tL, tR, _native.K_GSW_AGG)
+            taps = 2 * count_taps(H, W, win, maxD, minD)          # left- and right-referenced pass (_passive.cpp:428-548, 551-665)
+            nD = maxD - minD + 1
+            achieved = GSW_OPS_PER_TAP * taps / (k_ms * 1e-3) if k_ms else None
+            res[name] = {"matcher": "StereoGSW (+ left-right check and fill, always on)", "H": H, "W": W, "maxDisparity": maxD,
+                         "minDisparity": minD, "winSize": win, "gamma": GSW_GAMMA, "fMax": GSW_FMAX, "iterations": GSW_ITER,
+                         "ms_per_step": wall, "value": H * W * nD / (wall * 1e-3) / 1e6, "unit": "MPixels*disp/s",
+                         "checksum": checksum,
+                         "roofline": {"bound": "valu", "kernel": "gsw_aggregate_kernel (all launches of a step)", "kernel_ms": k_ms,
+                                      "taps": taps, "lane_ops_per_tap": GSW_OPS_PER_TAP, "tap_instructions": GSW_TAP_INSTRUCTIONS,
+                                      "achieved": achieved, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
+                                      "frac": achieved / VALU_PEAK_LANEOPS if achieved else None,
+                                      "hbm": {"algorithmic_bytes_per_step": GSW_ALGO_BYTES_PER_PIXEL * H * W,
+                                              "frac": GSW_ALGO_BYTES_PER_PIXEL * H * W / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else None}}}
+        except Exception as e:      # noqa: BLE001
+            res[name] = {"error": repr(e)[:200]}
+    return res
 
 
 def main():
@@ -144,7 +280,9 @@ def main():
     ap.add_argument("--consistent", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations (extra JSON key `others`)")
+    ap.add_argument("--cpu-rows-per-thread", type=int, default=2,
+                    help="cpu_baseline strip height in rows per host thread (the reference schedules one row per job)")
     ap.add_argument("--with-alternate", action="store_true",
                     help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
     args = ap.parse_args()
@@ -230,15 +368,9 @@ def main():
         algo_bytes = ALGO_BYTES_PER_PIXEL * rows_here * W
         taps_here = count_taps(H, W, win, maxD, minD, r0, rows_here)
         achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        achieved_ops = VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) if k_ms > 0 else None
         geom = _native.asw_geometry(W, rows_here, win, maxD, minD)
-        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (tools/prof_bench.sh), if committed
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-        if world == 1 and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = next(v.get("hbm_bytes_per_launch") for k, v in tj.items() if "asw_aggregate_kernel" in k)
-            except Exception:      # noqa: BLE001
-                traffic = None
+        traffic, traffic_source, issue = replayed_counters(args.config, k_ms) if world == 1 else (None, None, None)
         line = {
             "metric": "disparity MPixels/s (H*W*nDisp per second)",
             "value": H * W * nD / per_step / 1e6,
@@ -255,31 +387,22 @@ def main():
                                    (args.config, W, H, maxD, minD, win, GAMMA_C, GAMMA_P, bool(args.consistent)),
                        "parallelism": "1 GPU, whole frame" if world == 1 else "row strips x%d, RCCL halo exchange + all_gather" % world,
                        "launch": geom, "checksum": checksum},
-            "roofline": {"bound": "hbm", "kernel": "asw_aggregate_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved_gbs / HBM_PEAK_GBS) if achieved_gbs else None,
-                         "traffic": traffic,
+            # the bound that binds: fp32 VALU issue (no MFMA on this path, as north_star prescribes; HBM is ~3 orders
+            # of magnitude away, kept as roofline.hbm because north_star names it)
+            "roofline": {"bound": "valu", "kernel": "asw_aggregate_kernel", "achieved": achieved_ops, "peak": VALU_PEAK_LANEOPS,
+                         "unit": "lane-ops/s", "frac": (achieved_ops / VALU_PEAK_LANEOPS) if achieved_ops else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": k_ms, "launches": launches[_native.K_ASW_AGG],
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "VALU-bound stencil: see 'valu'; HBM figure reported because north_star asks for it"},
-            "valu": {"taps_per_launch": taps_here, "lane_ops_per_tap": VALU_OPS_PER_TAP,
-                     "achieved_lane_ops_per_s": VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) if k_ms > 0 else None,
-                     "peak_lane_ops_per_s": VALU_PEAK_LANEOPS,
-                     "frac": (VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) / VALU_PEAK_LANEOPS) if k_ms > 0 else None},
+                         "taps_per_launch": taps_here, "lane_ops_per_tap": VALU_OPS_PER_TAP,
+                         "tap_instructions": VALU_TAP_INSTRUCTIONS,
+                         "peak_definition": "256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles) = 157.3 TFLOP/s fp32",
+                         "issue": issue,
+                         "hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (achieved_gbs / HBM_PEAK_GBS) if achieved_gbs else None,
+                                 "algorithmic_bytes_per_launch": algo_bytes,
+                                 "note": "the roofline north_star names; not binding for this kernel"}},
             "kernels_ms_per_step": {_native.lib().ssamd_kernel_name(i).decode(): ms[i] / args.steps for i in range(_native.K_COUNT) if launches[i]},
         }
-        # VALU issue rate: instruction count per launch from the committed rocprofv3 PMC pass (like `traffic`),
-        # against the plain-fp32 issue rate measured on this chip by tools/ubench_valu.hip
-        vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % args.config)
-        if world == 1 and os.path.exists(vpath) and k_ms > 0:
-            try:
-                vj = json.load(open(vpath))
-                rate = vj["SQ_INSTS_VALU_per_launch"] / (k_ms * 1e-3) / 1024 / 1e9          # 256 CUs x 4 SIMDs
-                line["valu"]["issue"] = {"wave_instructions_per_launch": vj["SQ_INSTS_VALU_per_launch"],
-                                         "achieved_G_wave_instr_per_s_per_simd": rate,
-                                         "plain_fp32_peak_G_wave_instr_per_s_per_simd": vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"],
-                                         "frac": rate / vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"]}
-            except Exception:      # noqa: BLE001
-                pass
         if world == 1 and not args.consistent and args.with_alternate:
             # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
             alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
@@ -293,12 +416,15 @@ def main():
             line["alternate_rows_mode"] = {"ms_per_step": (time.perf_counter() - ta) / 3 * 1e3,
                                            "percent_pixels_differing_from_exact": 100.0 * float((alt_map != out).float().mean()),
                                            "note": "opt-in StereoASW(alternate=True); not the reference's output, never `value`"}
+        if world == 1 and not args.no_others:
+            line["others"] = others(dev, args.seed)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, args.seed, args.cpu_budget)
+            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread)
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
             # the CPU baseline computed (matched as a stand-alone sub-image by both)
             try:
-                ref_map = np.load(cb.pop("map_file"))
+                ref_map = np.load(cb["map_file"])
+                os.remove(cb["map_file"])
                 r0s, rws = cb["strip_row0"], cb["strip_rows"]
                 gpu_map = matcher.compute(np.ascontiguousarray(L[r0s:r0s + rws]), np.ascontiguousarray(R[r0s:r0s + rws]))
                 diff = np.abs(gpu_map.astype(np.int32) - ref_map.astype(np.int32))
@@ -310,6 +436,8 @@ def main():
             line["cpu_baseline"] = cb
             if cb["value"]:
                 line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+                if cb.get("hoisted", {}).get("value"):
+                    line["speedup_vs_cpu_hoisted_port"] = line["value"] / cb["hoisted"]["value"]
         result = json.dumps(line)
     else:
         result = None
