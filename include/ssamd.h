@@ -21,8 +21,10 @@
  *   - every function returns 0 on success or a negative SSAMD_E* code; a
  *     human-readable message for the calling thread is at ssamd_last_error().
  *   - the library never keeps a caller pointer after returning.
- *   - calls are serialised per process by an internal mutex (ctypes releases the
- *     GIL during the call, the reference holds it: blocking semantics are kept).
+ *   - calls are serialised PER DEVICE by an internal mutex (ctypes releases the
+ *     GIL during the call, the reference holds it: blocking semantics are kept);
+ *     threads that target different devices run concurrently.
+ *   - an entry point leaves the calling thread's current HIP device as it found it.
  *   - there is NO CPU fallback: without a HIP device every compute entry point
  *     fails with SSAMD_ENODEVICE.
  */
@@ -66,6 +68,23 @@ int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width,
               int winSize, int maxDisparity, int minDisparity,
               int gamma, float fMax, int iterations, int bins,
               int16_t *disparity, int device);
+
+/* ---- the same operators over several GPUs of one process ------------------- */
+/* The frame is cut into n_devices contiguous row strips (heights differ by at most one row; empty when there are
+ * more devices than rows); strip k, with its winSize/2 halo rows taken straight from the host arrays, is uploaded to
+ * devices[k], matched there and copied back into rows of `disparity` -- one host thread per device, so copies and
+ * kernels of all devices overlap.  Rows are the reference's independent jobs (_passive.cpp:372-374) and the
+ * left-right check / occlusion filling are row-local (251-285), so the result is bit-identical to ssamd_asw /
+ * ssamd_gsw on one device.  devices: distinct non-negative HIP ordinals.  No reference counterpart (the reference
+ * has no device); SURVEY.md section 5 `devices=` extension of StereoASW / StereoGSW.compute. */
+int ssamd_asw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    double gammaC, double gammaP, int consistent,
+                    int16_t *disparity, const int *devices, int n_devices);
+int ssamd_gsw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    int gamma, float fMax, int iterations, int bins,
+                    int16_t *disparity, const int *devices, int n_devices);
 
 /* ---- device-buffer operators (asynchronous on `stream`) -------------------- */
 /* d_img1/d_img2: device pointers to a [height][width][3] sub-image (for a row

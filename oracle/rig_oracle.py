@@ -9,7 +9,8 @@ reference makes and that this repo runs as HIP kernels:
   reproject       -- cv2.reprojectImageTo3D(disparity, Q) called by get3DPoints (_rigs.py:628)
 
 PARITY UNPINNED: OpenCV is not installed in this environment, so these restatements of the
-published OpenCV semantics (fixed-point bilinear with 5 fractional bits; homogeneous divide)
+published OpenCV semantics (imgwarp.cpp: map coordinates cvRound-ed to 1/32 pixel, 15-bit integer bilinear
+weights summing to 32768, FixedPtCast (sum + 16384) >> 15 so that ties round up; homogeneous divide)
 cannot be checked against cv2 itself.  They pin the HIP kernels and the numpy host path against
 each other only.  Only tests/ may import this module.
 """
@@ -33,14 +34,17 @@ def remap_bilinear(img, mapx, mapy, nearest=False):
                 continue
             qx, qy = int(np.rint(mx * 32.0)), int(np.rint(my * 32.0))
             x0, y0 = qx >> 5, qy >> 5                      # floor division, also for negatives
-            fx, fy = (qx & 31) / 32.0, (qy & 31) / 32.0
-            acc = np.zeros(img.shape[2], np.float64)
-            for dy, wy in ((0, 1.0 - fy), (1, fy)):
-                for dx, wx in ((0, 1.0 - fx), (1, fx)):
-                    xx, yy = x0 + dx, y0 + dy
-                    if 0 <= xx < Ws and 0 <= yy < Hs:
-                        acc += wy * wx * img[yy, xx].astype(np.float64)
-            out[y, x] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+            fx, fy = qx & 31, qy & 31
+            # OpenCV's BilinearTab_i entry for (fy, fx): shorts, round(weight * 32768), here exact
+            tab = [[(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32], [fy * (32 - fx) * 32, fy * fx * 32]]
+            for ch in range(img.shape[2]):
+                total = 0
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        xx, yy = x0 + dx, y0 + dy
+                        if 0 <= xx < Ws and 0 <= yy < Hs:
+                            total += tab[dy][dx] * int(img[yy, xx, ch])
+                out[y, x, ch] = min(255, max(0, (total + (1 << 14)) >> 15))
     return out
 
 

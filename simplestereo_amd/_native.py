@@ -44,6 +44,10 @@ def lib():
     L.ssamd_asw.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
     L.ssamd_gsw.restype = I
     L.ssamd_gsw.argtypes = [P, P, I, I, I, I, I, I, F, I, I, P, I]
+    L.ssamd_asw_multi.restype = I
+    L.ssamd_asw_multi.argtypes = [P, P, I, I, I, I, I, D, D, I, P, ctypes.POINTER(I), I]
+    L.ssamd_gsw_multi.restype = I
+    L.ssamd_gsw_multi.argtypes = [P, P, I, I, I, I, I, I, F, I, I, P, ctypes.POINTER(I), I]
     L.ssamd_asw_device.restype = I
     L.ssamd_asw_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_gsw_device.restype = I

@@ -59,8 +59,11 @@ def _distort(x, y, dist):
     return xd, yd
 
 
-def _undistort_points(pts, K, distCoeffs, R=None, iterations=20):
-    """cv2.undistortPoints semantics: pixel -> normalised, iterative undistortion, then R."""
+def _undistort_points(pts, K, distCoeffs, R=None, iterations=5):
+    """cv2.undistortPoints semantics: pixel -> normalised, iterative undistortion, then R.
+    ``iterations`` = 5 is OpenCV's default termination (TermCriteria(MAX_ITER, 5, 0.01) in cv::undistortPoints,
+    modules/calib3d/src/undistort.dispatch.cpp), which the reference's ``_getCorners`` inherits
+    (reference rectification.py:125-156)."""
     K = np.asarray(K, dtype=np.float64)
     dist = _dist_vector(distCoeffs)
     pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
@@ -102,8 +105,14 @@ def _init_undistort_rectify_map(K, distCoeffs, R, newK, size):
 
 
 def _remap(img, mapx, mapy, interpolation=INTER_LINEAR):
-    """cv2.remap with BORDER_CONSTANT(0).  Bilinear weights are quantised to 1/32 px like
-    OpenCV's fixed-point path (INTER_BITS = 5)."""
+    """cv2.remap with BORDER_CONSTANT(0), restating OpenCV's published arithmetic
+    (modules/imgproc/src/imgwarp.cpp: ``remap`` converts float maps with ``cvRound(map * INTER_TAB_SIZE)``,
+    INTER_BITS = 5; ``initInterTab2D`` builds 15-bit integer weights, INTER_REMAP_COEF_BITS = 15 -- with 5-bit
+    fractions they are exactly a*b*32 and sum to 32768; ``remapBilinear`` for uint8 ends in
+    ``FixedPtCast<int, uchar, 15>``: ``(sum + (1 << 14)) >> 15``, so ties round UP, not to even).
+    Integer images take that fixed-point path, with the common factor 32 divided out: ``(S + 512) >> 10``;
+    float images blend in floating point like OpenCV's float path.  cv2 is absent in this environment: parity
+    with cv2.remap itself stays unpinned (reference call: _rigs.py:564-565)."""
     img = np.asarray(img)
     squeeze = img.ndim == 2
     src = img[:, :, None] if squeeze else img
@@ -117,21 +126,22 @@ def _remap(img, mapx, mapy, interpolation=INTER_LINEAR):
     elif interpolation == INTER_LINEAR:
         q = np.rint(mapx.astype(np.float64) * 32).astype(np.int64)
         r = np.rint(mapy.astype(np.float64) * 32).astype(np.int64)
-        x0, fx = q >> 5, (q & 31) / 32.0
-        y0, fy = r >> 5, (r & 31) / 32.0
-        acc = np.zeros(mapx.shape + (src.shape[2],), np.float64)
-        for dy, wy in ((0, 1 - fy), (1, fy)):
-            for dx, wx in ((0, 1 - fx), (1, fx)):
+        x0, fx = q >> 5, q & 31
+        y0, fy = r >> 5, r & 31
+        integer = np.issubdtype(src.dtype, np.integer)
+        acc = np.zeros(mapx.shape + (src.shape[2],), np.int64 if integer else np.float64)
+        for dy, wy in ((0, 32 - fy), (1, fy)):
+            for dx, wx in ((0, 32 - fx), (1, fx)):
                 xx, yy = x0 + dx, y0 + dy
                 ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
                 val = np.zeros_like(acc)
                 val[ok] = src[yy[ok], xx[ok]]
-                acc += val * (wy * wx)[..., None]
-        if np.issubdtype(src.dtype, np.integer):
+                acc += val * (wy * wx)[..., None]          # a*b in 0..1024
+        if integer:
             info = np.iinfo(src.dtype)
-            out = np.clip(np.rint(acc), info.min, info.max).astype(src.dtype)
+            out = np.clip((acc + 512) >> 10, info.min, info.max).astype(src.dtype)
         else:
-            out = acc.astype(src.dtype)
+            out = (acc / 1024.0).astype(src.dtype)
     else:
         raise NotImplementedError("only INTER_NEAREST (0) and INTER_LINEAR (1) are available without OpenCV")
     return np.ascontiguousarray(out[:, :, 0] if squeeze else out)

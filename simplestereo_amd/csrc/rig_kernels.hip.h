@@ -11,8 +11,12 @@
 
 namespace ssamd {
 
-// Bilinear weights are quantised to 1/32 pixel like OpenCV's fixed-point remap (INTER_BITS = 5);
-// source pixels outside the image contribute 0 (constant border).
+// OpenCV's published 8-bit bilinear arithmetic (modules/imgproc/src/imgwarp.cpp, remap / remapBilinear and
+// initInterTab2D): map coordinates are rounded to 1/32 pixel (INTER_BITS = 5, cvRound = half to even), the four
+// weights are 15-bit integers (INTER_REMAP_COEF_BITS = 15; with 5-bit fractions a*b*32 exactly, summing to 32768)
+// and the result is FixedPtCast: (sum + (1 << 14)) >> 15, i.e. ties round UP -- here with the common factor 32
+// divided out: (S + 512) >> 10, S = sum a*b*pixel, a, b in 0..32.  Source pixels outside the image contribute the
+// constant border value 0.
 __global__ __launch_bounds__(256) void remap_bgr_kernel(const uint8_t *__restrict__ src, int Hs, int Ws,
                                                         const float *__restrict__ mapx, const float *__restrict__ mapy,
                                                         uint8_t *__restrict__ dst, long long npix, int nearest)
@@ -30,20 +34,20 @@ __global__ __launch_bounds__(256) void remap_bgr_kernel(const uint8_t *__restric
         } else {
             const long long qx = llrint((double)mapx[p] * 32.0), qy = llrint((double)mapy[p] * 32.0);
             const long long x0 = qx >> 5, y0 = qy >> 5;
-            const double fx = (double)(qx & 31) / 32.0, fy = (double)(qy & 31) / 32.0;
-            double acc[3] = {0.0, 0.0, 0.0};
+            const int fx = (int)(qx & 31), fy = (int)(qy & 31);
+            int acc[3] = {0, 0, 0};
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const long long xx = x0 + dx, yy = y0 + dy;
                     if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs) {
-                        const double w = (dy ? fy : 1.0 - fy) * (dx ? fx : 1.0 - fx);
+                        const int w = (dy ? fy : 32 - fy) * (dx ? fx : 32 - fx);
                         const uint8_t *s = src + ((size_t)yy * Ws + xx) * 3;
                         acc[0] += w * s[0]; acc[1] += w * s[1]; acc[2] += w * s[2];
                     }
                 }
-            out[0] = (float)rint(acc[0]); out[1] = (float)rint(acc[1]); out[2] = (float)rint(acc[2]);
+            out[0] = (float)((acc[0] + 512) >> 10); out[1] = (float)((acc[1] + 512) >> 10); out[2] = (float)((acc[2] + 512) >> 10);
         }
         dst[3 * p] = (uint8_t)fminf(fmaxf(out[0], 0.f), 255.f);
         dst[3 * p + 1] = (uint8_t)fminf(fmaxf(out[1], 0.f), 255.f);

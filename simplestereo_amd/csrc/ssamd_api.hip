@@ -5,7 +5,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <list>
 #include <map>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -27,7 +30,10 @@ using namespace ssamd;
 namespace {
 
 thread_local std::string g_err;
-std::mutex g_mutex;
+// Locking: every device has its own context and its own mutex (Ctx::mu), so one process can drive several GPUs
+// concurrently through the operators (ssamd_*_multi does, one host thread per device).  g_geom_mutex guards the
+// small process-wide launch-geometry caches only and is never held across a HIP call.
+std::mutex g_geom_mutex;
 
 int fail(int code, const char *fmt, ...)
 {
@@ -93,19 +99,57 @@ struct Profile {
     }
 };
 
+// Small parameter-keyed device tables (ASW proximity weights per (winSize, gammaP), GSW weight table per gamma):
+// a matcher that alternates between parameter sets finds its table again instead of re-uploading it behind a
+// stream synchronisation.  An entry owns its host copy, so the upload is an ordinary asynchronous copy on the
+// calling stream; later calls on other streams are ordered behind it by ScratchOrder.
+struct TableEntry {
+    int k0 = 0; double k1 = 0;
+    DevBuf dev;
+    std::vector<float> host;
+};
+struct TableCache {
+    std::list<TableEntry> entries;       // most recently used first
+    size_t max_entries;
+    explicit TableCache(size_t n) : max_entries(n) {}
+    TableEntry *find(int k0, double k1)
+    {
+        for (auto it = entries.begin(); it != entries.end(); ++it)
+            if (it->k0 == k0 && it->k1 == k1) {
+                entries.splice(entries.begin(), entries, it);
+                return &entries.front();
+            }
+        return nullptr;
+    }
+};
+
 struct Ctx {
+    std::mutex mu;                      // serialises the calls on this device
     int dev = -1;
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
-    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, prox, costs, gswTab, lab, altq;
-    // cached small tables
-    int prox_win = -1; double prox_gammaP = -1;
-    int gsw_gamma = -1; float gsw_fmax = -1.f;
+    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq;
+    TableCache proxTabs{8}, gswTabs{4};
+    std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
     Profile prof;
 };
 
 Ctx g_ctx[16];
+
+// The calling thread's current HIP device is restored when an entry point returns: an operator asked to run on
+// device k must not leave the caller's later allocations or launches on device k.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// hipFuncSetAttribute costs a runtime round trip: ask only when a launch needs more dynamic LDS than the kernel
+// has been granted on this device so far
+int grant_dyn_lds(Ctx &c, const void *kernel, int bytes);
 
 struct Timed {   // brackets one kernel launch with events when profiling is on
     Ctx &c; hipStream_t s; int slot; hipEvent_t a = nullptr, b = nullptr;
@@ -119,17 +163,27 @@ struct Timed {   // brackets one kernel launch with events when profiling is on
     }
 };
 
-int get_ctx(int device, Ctx **out)
+// A locked device context: makes `device` (-1: the calling thread's current one) current for the duration of the
+// entry point, takes that device's mutex and restores the caller's device afterwards.
+struct CtxLock {
+    DeviceGuard guard;                   // destroyed last: restores the caller's device after the unlock
+    std::unique_lock<std::mutex> lk;
+    Ctx *c = nullptr;
+    Ctx *operator->() { return c; }
+    Ctx &operator*() { return *c; }
+};
+
+int get_ctx(int device, CtxLock &out)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(SSAMD_ENODEVICE, "no HIP device visible: libssamd has no CPU fallback");
-    if (device < 0) {
-        if (hipGetDevice(&device) != hipSuccess) device = 0;
-    }
+    if (device < 0) device = out.guard.saved >= 0 ? out.guard.saved : 0;
     if (device >= n || device >= 16) return fail(SSAMD_EINVAL, "device ordinal %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
     Ctx &c = g_ctx[device];
+    out.lk = std::unique_lock<std::mutex>(c.mu);
+    out.c = &c;
     if (c.dev < 0) {
         c.dev = device;
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
@@ -148,12 +202,20 @@ int get_ctx(int device, Ctx **out)
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_lin100), lut, sizeof(lut)));
         c.lut_ready = true;
     }
-    *out = &c;
+    return SSAMD_OK;
+}
+
+int grant_dyn_lds(Ctx &c, const void *kernel, int bytes)
+{
+    int &granted = c.max_dyn_lds[kernel];
+    if (bytes <= granted || bytes <= 48 * 1024) return SSAMD_OK;     // 48 KiB need no opt-in
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    granted = bytes;
     return SSAMD_OK;
 }
 
 // The scratch buffers (pixel records, WTA keys, tables) are shared by every call on a device.  Calls are
-// serialised on the host by g_mutex; across streams the next call's stream waits for the previous call's
+// serialised on the host by the device's mutex; across streams the next call's stream waits for the previous call's
 // last kernel, so callers may use any stream without synchronising between operators.
 struct ScratchOrder {
     Ctx &c; hipStream_t s;
@@ -292,17 +354,18 @@ void asw_pick_e_scheme(AswGeom &g, int win)
 int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::vector<AswGeom> *shortlist = nullptr);
 
 // The search walks a few thousand candidate tiles (0.1-0.3 ms on the host): remember the answer per problem shape,
-// a video stream asks the same question every frame.  (Callers hold g_mutex.)
+// a video stream asks the same question every frame.  (Both maps are guarded by g_geom_mutex.)
 std::map<std::array<int, 4>, AswGeom> g_asw_geom_cache;
 std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached geometry was picked by measurement
 // autotuning mode: 1 always, 0 never, -1 (default) only for small problems, where the ~50 trial launches cost
 // at most about 0.2 s once and where the cost model is least reliable
-int g_autotune = getenv("SSAMD_AUTOTUNE") ? (atoi(getenv("SSAMD_AUTOTUNE")) > 0 ? 1 : (atoi(getenv("SSAMD_AUTOTUNE")) < 0 ? -1 : 0)) : -1;
+std::atomic<int> g_autotune{getenv("SSAMD_AUTOTUNE") ? (atoi(getenv("SSAMD_AUTOTUNE")) > 0 ? 1 : (atoi(getenv("SSAMD_AUTOTUNE")) < 0 ? -1 : 0)) : -1};
 constexpr double ASW_AUTOTUNE_SMALL_TAPS = 3.0e10;      // window taps per call (about 3-4 ms of kernel time)
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
     if (getenv("SSAMD_ASW_GEOM")) return asw_search_geometry(best, W, rows, win, nD);      // tuning hook: never cached
+    std::lock_guard<std::mutex> glk(g_geom_mutex);
     const std::array<int, 4> key{W, rows, win, nD};
     auto it = g_asw_geom_cache.find(key);
     if (it != g_asw_geom_cache.end()) { best = it->second; return SSAMD_OK; }
@@ -411,21 +474,36 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
     return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no ASW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
 }
 
-int upload_prox(Ctx &c, int win, double gammaP, hipStream_t s)
+// Proximity weights exp(-|t|/gammaP) of the window taps (_passive.cpp:360-364), cached per (winSize, gammaP).
+int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
 {
-    if (c.prox_win == win && c.prox_gammaP == gammaP) return SSAMD_OK;
+    if (TableEntry *e = c.proxTabs.find(win, gammaP)) { *out = (const float *)e->dev.ptr; return SSAMD_OK; }
+    if (c.proxTabs.entries.size() >= c.proxTabs.max_entries) {
+        // evicting frees device memory a launch in flight may still read: the one place that waits (rare: more
+        // than eight parameter sets alternating on one device)
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(c.proxTabs.entries.back().dev.ptr);
+        c.proxTabs.entries.pop_back();
+    }
+    c.proxTabs.entries.emplace_front();
+    TableEntry &e = c.proxTabs.entries.front();
+    e.k0 = win; e.k1 = gammaP;
     const int p = win / 2;
-    std::vector<float> t((size_t)win * win);
-    for (int i = 0; i < win; ++i)            // _passive.cpp:360-364
+    e.host.resize((size_t)win * win);
+    for (int i = 0; i < win; ++i)
         for (int j = 0; j < win; ++j) {
             const double di = i - p, dj = j - p;
-            t[(size_t)i * win + j] = (float)std::exp(-std::sqrt(di * di + dj * dj) / gammaP);
+            e.host[(size_t)i * win + j] = (float)std::exp(-std::sqrt(di * di + dj * dj) / gammaP);
         }
-    int rc = c.prox.reserve(t.size() * 4);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));        // a previous launch may still read the old table
-    HIP_TRY(hipMemcpy(c.prox.ptr, t.data(), t.size() * 4, hipMemcpyHostToDevice));
-    c.prox_win = win; c.prox_gammaP = gammaP;
+    int rc = e.dev.reserve(e.host.size() * 4);
+    if (rc) { c.proxTabs.entries.pop_front(); return rc; }
+    hipError_t he = hipMemcpyAsync(e.dev.ptr, e.host.data(), e.host.size() * 4, hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) {
+        (void)hipFree(e.dev.ptr);
+        c.proxTabs.entries.pop_front();
+        return fail(SSAMD_EHIP, "hipMemcpyAsync(proximity table) failed: %s", hipGetErrorString(he));
+    }
+    *out = (const float *)e.dev.ptr;
     return SSAMD_OK;
 }
 
@@ -446,7 +524,9 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
     if (rows <= 0) return SSAMD_OK;
     Timed t(c, s, slot);
     if (lrcheck) {
-        const size_t lds = (((size_t)W * 2 + 15) & ~(size_t)15) + W;
+        const size_t lds = (((size_t)W * 2 + 15) & ~(size_t)15) + W;      // up to 96 KiB at the 32767-column limit
+        int rc = grant_dyn_lds(c, (const void *)lr_check_fill_kernel, (int)lds);
+        if (rc) return rc;
         hipLaunchKernelGGL(lr_check_fill_kernel, dim3(rows), dim3(256), lds, s, (const u64 *)c.keyL.ptr,
                            (const u64 *)c.keyR.ptr, d_disp, rows, W);
     } else {
@@ -483,8 +563,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     const std::array<int, 4> shape{W, grows, win, nD};
     std::vector<AswGeom> trial;
     const double call_taps = (double)W * grows * nD * win * win;
-    const bool tune_now = g_autotune > 0 || (g_autotune < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS);
-    if (tune_now && nD >= 1 && !getenv("SSAMD_ASW_GEOM") && !g_asw_geom_tuned.count(shape)) {
+    const int tune_mode = g_autotune.load();
+    const bool tune_now = tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS);
+    bool tuned_already;
+    { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_asw_geom_tuned.count(shape) != 0; }
+    if (tune_now && nD >= 1 && !getenv("SSAMD_ASW_GEOM") && !tuned_already) {
         AswGeom tmp;
         if (asw_search_geometry(tmp, W, grows, win, nD, &trial) != SSAMD_OK || trial.size() < 2) trial.clear();
     }
@@ -503,13 +586,14 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     if (nD >= 1) {
         if ((rc = c.recL.reserve(npix * sizeof(PixRec)))) return rc;
         if ((rc = c.recR.reserve(npix * sizeof(PixRec)))) return rc;
-        if ((rc = upload_prox(c, win, gammaP, s))) return rc;
+        const float *d_prox = nullptr;
+        if ((rc = get_prox(c, win, gammaP, s, &d_prox))) return rc;
         const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
         if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
         if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
 
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
-        a.prox = (const float *)c.prox.ptr;
+        a.prox = d_prox;
         a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
         a.costs = d_costs;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
@@ -526,7 +610,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             if (g.Rx == 4)
                 kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true, 4> : asw_aggregate_kernel<false, true, 4>)
                                : (d_costs ? asw_aggregate_kernel<true, false, 4> : asw_aggregate_kernel<false, false, 4>);
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes));
+            if (int grc = grant_dyn_lds(c, (const void *)kern, g.lds_bytes)) return grc;
             hipLaunchKernelGGL(kern, grid, block, g.lds_bytes, s, a);
             HIP_TRY(hipGetLastError());
             return SSAMD_OK;
@@ -555,8 +639,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 if (cand_ms[ci] < best_ms * (ci == 0 ? 1.0f : 0.985f)) { best_ms = cand_ms[ci]; fastest = trial[ci]; }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
-            g_asw_geom_cache[shape] = fastest;
-            g_asw_geom_tuned[shape] = true;
+            {
+                std::lock_guard<std::mutex> glk(g_geom_mutex);
+                g_asw_geom_cache[shape] = fastest;
+                g_asw_geom_tuned[shape] = true;
+            }
             a.g = fastest;
         }
         {
@@ -580,7 +667,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         if ((rc = c.altq.reserve((size_t)f.cap * 8 + 16))) return rc;
         f.ctr = (unsigned int *)c.altq.ptr; f.queue = (u64 *)((char *)c.altq.ptr + 16);
         HIP_TRY(hipMemsetAsync(f.ctr, 0, 16, s));
-        f.recL = (const PixRec *)c.recL.ptr; f.recR = (const PixRec *)c.recR.ptr; f.prox = (const float *)c.prox.ptr;
+        f.recL = (const PixRec *)c.recL.ptr; f.recR = (const PixRec *)c.recR.ptr; f.prox = a.prox;
         f.disp = d_disp; f.key = (u64 *)c.keyL.ptr;
         f.H = H; f.W = W; f.win = win; f.pad = p; f.minD = minD; f.maxD = maxD;
         f.kC = (float)(-1.4426950408889634 / gammaC);
@@ -631,6 +718,7 @@ int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)      //
 {
     static std::map<std::array<int, 4>, GswGeom> cache;
     if (getenv("SSAMD_GSW_GEOM")) return gsw_search_geometry(best, W, rows, win, nD);
+    std::lock_guard<std::mutex> glk(g_geom_mutex);
     const std::array<int, 4> key{W, rows, win, nD};
     auto it = cache.find(key);
     if (it != cache.end()) { best = it->second; return SSAMD_OK; }
@@ -694,19 +782,31 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
 
 // support weight as a function of the integer squared colour distance, in the reference's
 // arithmetic: fl32 distance (sqrt in double), float division by gamma, float exp (_passive.cpp:457-463, 495)
-int upload_gsw_table(Ctx &c, int gamma, hipStream_t s)
+int get_gsw_table(Ctx &c, int gamma, hipStream_t s, const float **out)
 {
-    if (c.gsw_gamma == gamma && c.gswTab.ptr) return SSAMD_OK;
-    std::vector<float> tab(GSW_TAB_SIZE);
+    if (TableEntry *e = c.gswTabs.find(gamma, 0.0)) { *out = (const float *)e->dev.ptr; return SSAMD_OK; }
+    if (c.gswTabs.entries.size() >= c.gswTabs.max_entries) {
+        HIP_TRY(hipDeviceSynchronize());         // see get_prox
+        (void)hipFree(c.gswTabs.entries.back().dev.ptr);
+        c.gswTabs.entries.pop_back();
+    }
+    c.gswTabs.entries.emplace_front();
+    TableEntry &e = c.gswTabs.entries.front();
+    e.k0 = gamma; e.k1 = 0.0;
+    e.host.resize(GSW_TAB_SIZE);
     for (int v = 0; v < GSW_TAB_SIZE; ++v) {
         const float dist = (float)(0.0f + std::sqrt((double)v));
-        tab[v] = expf(-dist / gamma);
+        e.host[v] = expf(-dist / gamma);
     }
-    int rc = c.gswTab.reserve(tab.size() * 4);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(c.gswTab.ptr, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-    c.gsw_gamma = gamma;
+    int rc = e.dev.reserve(e.host.size() * 4);
+    if (rc) { c.gswTabs.entries.pop_front(); return rc; }
+    hipError_t he = hipMemcpyAsync(e.dev.ptr, e.host.data(), e.host.size() * 4, hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) {
+        (void)hipFree(e.dev.ptr);
+        c.gswTabs.entries.pop_front();
+        return fail(SSAMD_EHIP, "hipMemcpyAsync(GSW weight table) failed: %s", hipGetErrorString(he));
+    }
+    *out = (const float *)e.dev.ptr;
     return SSAMD_OK;
 }
 
@@ -726,7 +826,8 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     if (nD >= 1) {
         // packed pixels live in the (larger) ASW record buffers: 4 B/pixel
         if ((rc = c.recL.reserve(npix * 4)) || (rc = c.recR.reserve(npix * 4))) return rc;
-        if ((rc = upload_gsw_table(c, gamma, s))) return rc;
+        const float *d_tab = nullptr;
+        if ((rc = get_gsw_table(c, gamma, s, &d_tab))) return rc;
         const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
         const long long np = (long long)(r1 - r0) * W;
         const int blocks = (int)std::min<long long>((np + 255) / 256, 256 * 8);
@@ -740,12 +841,12 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         }
         GswArgs a;
         if ((rc = gsw_choose_geometry(a.g, W, rows, win, nD))) return rc;
-        a.tab = (const float *)c.gswTab.ptr;
+        a.tab = d_tab;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.iterations = iterations; a.fMax = fMax;
         const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + a.g.Ty - 1) / a.g.Ty, a.g.nchunks), block(a.g.threads);
         auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, a.g.lds_bytes));
+        if ((rc = grant_dyn_lds(c, (const void *)kernel, a.g.lds_bytes))) return rc;
         for (int pass = 0; pass < 2; ++pass) {
             a.right = pass;
             a.ref = (const uint32_t *)(pass ? c.recR.ptr : c.recL.ptr);
@@ -762,6 +863,128 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
 }  // namespace
 
 // =================================================================== C ABI
+namespace {
+
+// ---- host-buffer paths: H2D copy of rows [in0, in1) of both images, kernels on output rows [o0, o1), D2H copy.
+// Used for the whole image (ssamd_asw / ssamd_gsw) and, one host thread per device, for the row strips of
+// ssamd_*_multi: output row y needs input rows y-pad .. y+pad only and the left-right check and occlusion filling
+// are row-local (_passive.cpp:38-40, 60-62, 251-285), so a strip that carries its halo reproduces the rows of the
+// whole-image result bit for bit.
+struct HostJob {
+    const uint8_t *img1, *img2;
+    int H, W, win, maxD, minD;
+    int o0, o1;                    // output rows of the full image
+    int16_t *disparity;            // full-image output [H][W]
+    // ASW
+    double gammaC, gammaP; int consistent; float *costs; bool alternate;
+    // GSW
+    int gamma; float fMax; int iterations;
+};
+
+int asw_host_rows(const HostJob &j, int device)
+{
+    CtxLock c;
+    int rc = get_ctx(device, c);
+    if (rc) return rc;
+    if ((rc = check_common(j.H, j.W, j.win, j.minD, j.maxD, j.o0, j.o1 - j.o0))) return rc;
+    const int p = j.win / 2, in0 = std::max(0, j.o0 - p), in1 = std::min(j.H, j.o1 + p), rows = j.o1 - j.o0;
+    const size_t nb = (size_t)(in1 - in0) * j.W * 3, nout = (size_t)rows * j.W;
+    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
+    const size_t ncost = j.costs ? nout * (size_t)std::max(1, j.maxD - j.minD + 1) : 0;
+    if (j.costs && (rc = c->costs.reserve(ncost * 4))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, j.img1 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, j.img2 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    if (j.costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
+    rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
+                         j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr,
+                         j.costs ? (float *)c->costs.ptr : nullptr, s, j.alternate);
+    if (rc) return rc;
+    if (j.disparity)
+        HIP_TRY(hipMemcpyAsync(j.disparity + (size_t)j.o0 * j.W, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    if (j.costs) HIP_TRY(hipMemcpyAsync(j.costs, c->costs.ptr, ncost * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int gsw_host_rows(const HostJob &j, int device)
+{
+    CtxLock c;
+    int rc = get_ctx(device, c);
+    if (rc) return rc;
+    if ((rc = check_common(j.H, j.W, j.win, j.minD, j.maxD, j.o0, j.o1 - j.o0))) return rc;
+    const int p = j.win / 2, in0 = std::max(0, j.o0 - p), in1 = std::min(j.H, j.o1 + p), rows = j.o1 - j.o0;
+    const size_t nb = (size_t)(in1 - in0) * j.W * 3, nout = (size_t)rows * j.W;
+    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, j.img1 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, j.img2 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    rc = gsw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
+                         j.win, j.maxD, j.minD, j.gamma, j.fMax, j.iterations, (int16_t *)c->disp.ptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(j.disparity + (size_t)j.o0 * j.W, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+// Contiguous row strips whose heights differ by at most one row (empty when there are more devices than rows) --
+// the same cut as simplestereo_amd/strips.py::strip_bounds.  One host thread per strip: each takes its own device's lock, so the
+// copies and kernels of all devices overlap.  The first failing strip's code and message are returned.
+int run_strips(const HostJob &job, const int *devices, int n_devices, int (*fn)(const HostJob &, int))
+{
+    if (!devices || n_devices < 1) return fail(SSAMD_EINVAL, "devices must name at least one GPU");
+    if (n_devices > 16) return fail(SSAMD_EINVAL, "at most 16 devices");
+    for (int a = 0; a < n_devices; ++a) {
+        if (devices[a] < 0) return fail(SSAMD_EINVAL, "devices[%d] = %d: explicit non-negative ordinals only", a, devices[a]);
+        // test hook SSAMD_MULTI_ALLOW_REPEAT: a 1-GPU box exercises the strip cut with one device listed several
+        // times (the strips then simply queue on that device's mutex)
+        for (int b = 0; b < a && !getenv("SSAMD_MULTI_ALLOW_REPEAT"); ++b)
+            if (devices[a] == devices[b]) return fail(SSAMD_EINVAL, "device %d listed twice", devices[a]);
+    }
+    int rc = check_common(job.H, job.W, job.win, job.minD, job.maxD, 0, job.H);
+    if (rc) return rc;
+    const int base = job.H / n_devices, extra = job.H % n_devices;
+    std::vector<int> codes(n_devices, SSAMD_OK);
+    std::vector<std::string> msgs(n_devices);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_devices; ++k) {
+        HostJob j = job;
+        j.o0 = k * base + std::min(k, extra);
+        j.o1 = j.o0 + base + (k < extra ? 1 : 0);
+        if (j.o1 <= j.o0) continue;                      // more devices than rows: nothing for this one
+        const int dev = devices[k];
+        th.emplace_back([j, dev, k, fn, &codes, &msgs]() {
+            codes[k] = fn(j, dev);
+            if (codes[k]) msgs[k] = g_err;               // thread-local message of the worker
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_devices; ++k)
+        if (codes[k]) return fail(codes[k], "strip %d on device %d: %s", k, devices[k], msgs[k].c_str());
+    return SSAMD_OK;
+}
+
+HostJob asw_job(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, double gammaC,
+                double gammaP, int consistent, int16_t *disparity, float *costs, bool alternate)
+{
+    HostJob j{};
+    j.img1 = img1; j.img2 = img2; j.H = H; j.W = W; j.win = win; j.maxD = maxD; j.minD = minD; j.o0 = 0; j.o1 = H;
+    j.disparity = disparity; j.gammaC = gammaC; j.gammaP = gammaP; j.consistent = consistent; j.costs = costs;
+    j.alternate = alternate;
+    return j;
+}
+
+HostJob gsw_job(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, int gamma, float fMax,
+                int iterations, int16_t *disparity)
+{
+    HostJob j{};
+    j.img1 = img1; j.img2 = img2; j.H = H; j.W = W; j.win = win; j.maxD = maxD; j.minD = minD; j.o0 = 0; j.o1 = H;
+    j.disparity = disparity; j.gamma = gamma; j.fMax = fMax; j.iterations = iterations;
+    return j;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ssamd_abi_version(void) { return SSAMD_ABI_VERSION; }
@@ -784,15 +1007,11 @@ const char *ssamd_kernel_name(int slot)
 
 int ssamd_autotune(int on)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    const int before = g_autotune;
-    g_autotune = on > 0 ? 1 : (on < 0 ? -1 : 0);
-    return before;
+    return g_autotune.exchange(on > 0 ? 1 : (on < 0 ? -1 : 0));
 }
 
 int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!out) return fail(SSAMD_EINVAL, "out is NULL");
     int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
     if (rc) return rc;
@@ -807,7 +1026,6 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
 
 int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!out) return fail(SSAMD_EINVAL, "out is NULL");
     int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
     if (rc) return rc;
@@ -824,67 +1042,46 @@ int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
                      int16_t *d_disparity, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    Ctx *c;
-    int rc = get_ctx(-1, &c);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream);
 }
 
-static int asw_host(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, double gammaC,
-                    double gammaP, int consistent, int16_t *disparity, float *costs, int device, bool alternate = false)
-{
-    if (!img1 || !img2 || (!disparity && !costs)) return fail(SSAMD_EINVAL, "NULL buffer");
-    Ctx *c;
-    int rc = get_ctx(device, &c);
-    if (rc) return rc;
-    if ((rc = check_common(H, W, win, minD, maxD, 0, H))) return rc;
-    const size_t nb = (size_t)H * W * 3, nout = (size_t)H * W;
-    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
-    const size_t ncost = costs ? nout * (size_t)std::max(1, maxD - minD + 1) : 0;
-    if (costs && (rc = c->costs.reserve(ncost * 4))) return rc;
-    hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img1, nb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, nb, hipMemcpyHostToDevice, s));
-    if (costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
-    rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, H, W, 0, H, win, maxD, minD,
-                         gammaC, gammaP, consistent, (int16_t *)c->disp.ptr, costs ? (float *)c->costs.ptr : nullptr, s,
-                         alternate);
-    if (rc) return rc;
-    if (disparity) HIP_TRY(hipMemcpyAsync(disparity, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
-    if (costs) HIP_TRY(hipMemcpyAsync(costs, c->costs.ptr, ncost * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return SSAMD_OK;
-}
-
 int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
               int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    if (!disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
-                    disparity, nullptr, device);
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                                 disparity, nullptr, false), device);
+}
+
+int ssamd_asw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                    const int *devices, int n_devices)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return run_strips(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                              disparity, nullptr, false), devices, n_devices, asw_host_rows);
 }
 
 int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
                         int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    if (!disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent, disparity,
-                    nullptr, device, true);
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                                 disparity, nullptr, true), device);
 }
 
 int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int winSize,
                                int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
                                int16_t *d_disparity, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    Ctx *c;
-    int rc = get_ctx(-1, &c);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC,
                            gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream, true);
@@ -893,23 +1090,22 @@ int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int
 int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
                     int minDisparity, double gammaC, double gammaP, float *costs, int device)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    if (!costs) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (!img1 || !img2 || !costs) return fail(SSAMD_EINVAL, "NULL buffer");
     if (maxDisparity < minDisparity) return fail(SSAMD_EINVAL, "empty disparity range");
-    return asw_host(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, nullptr, costs,
-                    device);
+    return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, nullptr,
+                                 costs, false), device);
 }
 
 int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!img || !lab || height <= 0 || width <= 0) return fail(SSAMD_EINVAL, "bad argument");
-    Ctx *c;
-    int rc = get_ctx(device, &c);
+    CtxLock c;
+    int rc = get_ctx(device, c);
     if (rc) return rc;
     const size_t npix = (size_t)height * width;
     if ((rc = c->imgL.reserve(npix * 3)) || (rc = c->lab.reserve(npix * 12))) return rc;
     hipStream_t s = c->stream;
+    ScratchOrder order(*c, s);
     HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img, npix * 3, hipMemcpyHostToDevice, s));
     const int blocks = (int)std::min<size_t>((npix + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(bgr2lab_f32_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t *)c->imgL.ptr,
@@ -924,11 +1120,10 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int winSize, int maxDisparity, int minDisparity, int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     (void)bins;                       // never read by the reference either (_passive.cpp:410)
     if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    Ctx *c;
-    int rc = get_ctx(-1, &c);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
     if (rc) return rc;
     return gsw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gamma, fMax, iterations, d_disparity, (hipStream_t)stream);
@@ -937,35 +1132,30 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
 int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
               int minDisparity, int gamma, float fMax, int iterations, int bins, int16_t *disparity, int device)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     (void)bins;
     if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
-    Ctx *c;
-    int rc = get_ctx(device, &c);
-    if (rc) return rc;
-    if ((rc = check_common(height, width, winSize, minDisparity, maxDisparity, 0, height))) return rc;
-    const size_t nb = (size_t)height * width * 3, nout = (size_t)height * width;
-    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
-    hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img1, nb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, nb, hipMemcpyHostToDevice, s));
-    rc = gsw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, height, width, 0, height,
-                         winSize, maxDisparity, minDisparity, gamma, fMax, iterations, (int16_t *)c->disp.ptr, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(disparity, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return SSAMD_OK;
+    return gsw_host_rows(gsw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gamma, fMax, iterations,
+                                 disparity), device);
+}
+
+int ssamd_gsw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, int gamma, float fMax, int iterations, int bins, int16_t *disparity,
+                    const int *devices, int n_devices)
+{
+    (void)bins;
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return run_strips(gsw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gamma, fMax, iterations,
+                              disparity), devices, n_devices, gsw_host_rows);
 }
 
 int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
                            int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!d_src || !d_mapx || !d_mapy || !d_dst) return fail(SSAMD_EINVAL, "NULL buffer");
     if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
     if (interpolation != 0 && interpolation != 1) return fail(SSAMD_EINVAL, "only INTER_NEAREST (0) and INTER_LINEAR (1) are supported");
-    Ctx *c;
-    int rc = get_ctx(-1, &c);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const long long npix = (long long)dst_h * dst_w;
@@ -979,11 +1169,10 @@ int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const flo
 
 int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const double *Q, float *d_points, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!d_disparity || !Q || !d_points) return fail(SSAMD_EINVAL, "NULL buffer");
     if (h <= 0 || w <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
-    Ctx *c;
-    int rc = get_ctx(-1, &c);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     Mat4 q;
@@ -998,13 +1187,13 @@ int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const doubl
 
 int ssamd_debug_gsw_sqrt(int n, float *out)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
     if (!out || n <= 0 || n > GSW_TAB_SIZE) return fail(SSAMD_EINVAL, "bad argument");
-    Ctx *c;
-    int rc = get_ctx(-1, &c);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
     if (rc) return rc;
     if ((rc = c->lab.reserve((size_t)n * 4))) return rc;
     hipStream_t s = c->stream;
+    ScratchOrder order(*c, s);
     hipLaunchKernelGGL(gsw_sqrt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (float *)c->lab.ptr, n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->lab.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -1014,15 +1203,18 @@ int ssamd_debug_gsw_sqrt(int n, float *out)
 
 int ssamd_profile_enable(int on)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    for (auto &c : g_ctx) c.prof.on = on != 0;
+    for (auto &c : g_ctx) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.prof.on = on != 0;
+    }
     return SSAMD_OK;
 }
 
 int ssamd_profile_reset(void)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    DeviceGuard guard;
     for (auto &c : g_ctx) {
+        std::lock_guard<std::mutex> lk(c.mu);
         if (c.dev < 0) continue;
         (void)hipSetDevice(c.dev);
         c.prof.drain();
@@ -1034,17 +1226,15 @@ int ssamd_profile_reset(void)
 
 int ssamd_profile_read(double *ms, long long *launches)
 {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
+    DeviceGuard guard;
     for (int k = 0; k < SSAMD_K_COUNT; ++k) { if (ms) ms[k] = 0; if (launches) launches[k] = 0; }
     for (auto &c : g_ctx) {
+        std::lock_guard<std::mutex> lk(c.mu);
         if (c.dev < 0) continue;
         (void)hipSetDevice(c.dev);
         c.prof.drain();
         for (int k = 0; k < SSAMD_K_COUNT; ++k) { if (ms) ms[k] += c.prof.ms[k]; if (launches) launches[k] += c.prof.n[k]; }
     }
-    (void)hipSetDevice(cur);
     return SSAMD_OK;
 }
 

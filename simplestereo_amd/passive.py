@@ -31,6 +31,10 @@ Extensions (not in the reference): ``compute`` also accepts two CUDA/HIP
 ``torch.int16`` tensor on the same device without any host round trip; and both
 classes take one extra trailing keyword, ``device`` (default ``None`` = the
 process's current HIP device), the GPU index that host-array calls run on.
+``compute`` of both classes also takes an optional keyword ``devices=[i, j, ...]`` (host arrays only): the frame
+is cut into one row strip per listed GPU, each strip is matched on its own device concurrently and the map is
+reassembled on the host -- bit-identical to the one-GPU result, because rows are independent jobs in the
+reference as well (``_passive.cpp:372-374``).
 ``StereoASW`` also takes ``alternate`` (default ``False``): the faster
 "every other pixel" variant that the reference's docstring sketches as a todo
 (reference ``passive.py:43-46``) and never implemented.
@@ -101,6 +105,17 @@ def _device_index(device):
     if i < 0:
         raise ValueError("device must be None or a non-negative GPU index")
     return i
+
+
+def _device_list(devices):
+    """devices=[...] of compute(): distinct non-negative GPU indices as a C int array"""
+    try:
+        idx = [_c_int(d) for d in devices]
+    except TypeError:
+        raise ValueError("devices must be a sequence of GPU indices") from None
+    if not idx or any(i < 0 for i in idx):
+        raise ValueError("devices must be a non-empty sequence of distinct non-negative GPU indices")
+    return (ctypes.c_int * len(idx))(*idx), len(idx)
 
 
 def set_autotune(on=True):
@@ -178,15 +193,18 @@ class StereoASW():
             raise ValueError("alternate=True needs the whole image (no row strips)")
         return True
 
-    def compute(self, img1, img2):
+    def compute(self, img1, img2, devices=None):
         """
         Disparity map of a rectified BGR pair.
 
         img1, img2: left and right image, ``numpy.uint8`` arrays ``[H, W, 3]`` in OpenCV channel
         order (or two device tensors, see the module docstring).  Returns a new ``numpy.int16``
-        array ``[H, W]`` of left-referenced disparities.
+        array ``[H, W]`` of left-referenced disparities.  ``devices`` (extension, host arrays only):
+        list of GPU indices that share the frame as row strips.
         """
         if _is_device_tensor(img1) and _is_device_tensor(img2):
+            if devices is not None:
+                raise ValueError("devices=[...] applies to host arrays; device tensors are matched where they live")
             return self._compute_device(img1, img2)
         lib = _native.lib()
         if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
@@ -199,6 +217,12 @@ class StereoASW():
         H, W = a.shape[:2]
         out = np.empty((H, W), np.int16)
         try:
+            if devices is not None:
+                self._alternate(cons, whole_image=False)      # alternate=True raises: that mode takes whole images
+                arr, n = _device_list(devices)
+                _native.check(lib.ssamd_asw_multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
+                                                  out.ctypes.data, arr, n))
+                return out
             if self._alternate(cons):
                 _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
                                                       out.ctypes.data, dev))
@@ -281,9 +305,12 @@ class StereoGSW():
         return (_c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity), _c_int(self.gamma),
                 _c_double(self.fMax), _c_int(self.iterations), _c_int(self.bins))
 
-    def compute(self, img1, img2):
-        """Disparity map of a rectified 3-channel pair (uint8 [H,W,3]); returns int16 [H,W]."""
+    def compute(self, img1, img2, devices=None):
+        """Disparity map of a rectified 3-channel pair (uint8 [H,W,3]); returns int16 [H,W].
+        ``devices`` (extension, host arrays only): list of GPU indices that share the frame as row strips."""
         if _is_device_tensor(img1) and _is_device_tensor(img2):
+            if devices is not None:
+                raise ValueError("devices=[...] applies to host arrays; device tensors are matched where they live")
             return self._compute_device(img1, img2)
         lib = _native.lib()
         if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
@@ -296,6 +323,11 @@ class StereoGSW():
         H, W = a.shape[:2]
         out = np.empty((H, W), np.int16)
         try:
+            if devices is not None:
+                arr, n = _device_list(devices)
+                _native.check(lib.ssamd_gsw_multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gamma, fmax, it,
+                                                  bins, out.ctypes.data, arr, n))
+                return out
             _native.check(lib.ssamd_gsw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gamma, fmax, it, bins,
                                         out.ctypes.data, dev))
         except _native.NativeError as e:

@@ -24,7 +24,8 @@ def exportPLY(points3D, filepath, referenceImage=None, precision=6):
         File path for the PLY file (absolute or relative).
     referenceImage : numpy.ndarray, optional
         Image to take colours from: same number of points as `points3D`; last dimension 3 (BGR) or
-        1 / absent (intensity; integer images are written as int, others as float).
+        1 / absent (intensity; like the reference, only int64 images are written as ``int`` -- every
+        other dtype, uint8 included, as ``float`` in a field of width `precision`, reference points.py:62-80).
     precision : int
         Decimal places of the coordinates. Default 6.
     """
@@ -43,14 +44,14 @@ def exportPLY(points3D, filepath, referenceImage=None, precision=6):
             head += ["property uchar red", "property uchar green", "property uchar blue"]
             cols.append(img.reshape(-1, 3)[:, ::-1].astype(np.float64))
             fmt += ["%d"] * 3
-        elif np.issubdtype(img.dtype, np.integer):
+        elif np.issubdtype(img.dtype, np.int64):               # the reference's test (points.py:62)
             head.append("property int intensity")
             cols.append(img.reshape(-1, 1).astype(np.float64))
             fmt.append("%d")
         else:
             head.append("property float intensity")
             cols.append(img.reshape(-1, 1).astype(np.float64))
-            fmt.append("%.{p}f".format(p=precision))
+            fmt.append("%{p}f".format(p=precision))            # "{:{p}f}": width p, six decimals (points.py:78)
     head.append("end_header")
     with open(filepath, "w") as f:
         f.write("\n".join(head) + "\n")
@@ -60,7 +61,8 @@ def exportPLY(points3D, filepath, referenceImage=None, precision=6):
 def importPLY(filename, *properties):
     """
     Import values from an ASCII PLY file: the property columns `properties` (default 0, 1, 2 =
-    x, y, z) of every vertex line, as a float array of shape (number of vertices, len(properties)).
+    x, y, z) of every vertex line, as a float array of shape (number of vertices, len(properties));
+    an empty cloud gives shape (0,) like the reference's ``np.asarray([], dtype=float)`` (points.py:121).
     """
     if not properties:
         properties = (0, 1, 2)
@@ -69,7 +71,7 @@ def importPLY(filename, *properties):
             if line.rstrip().lower() == "end_header":
                 break
         data = np.loadtxt(f, dtype=float, ndmin=2)
-    return np.ascontiguousarray(data[:, list(properties)]) if data.size else np.zeros((0, len(properties)))
+    return np.ascontiguousarray(data[:, list(properties)]) if data.size else np.zeros((0,), dtype=float)
 
 
 def getAdimensional3DPoints(disparityMap):

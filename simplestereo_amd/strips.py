@@ -127,8 +127,18 @@ def match_strip(matcher, own_left, own_right, height, rank, world_size, group=No
     """
     pad = int(matcher.winSize) // 2
     subL, subR, out_row0, out_rows = exchange_halos(own_left, own_right, height, pad, rank, world_size, group)
-    strip = matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows)
+    strip = _match_rows(matcher, subL, subR, out_row0, out_rows)
     return gather_strips(strip, height, rank, world_size, group) if gather else strip
+
+
+def _match_rows(matcher, subL, subR, out_row0, out_rows):
+    """The kernels on one strip.  A rank whose strip is EMPTY (more ranks than image rows) has nothing to match --
+    the operators refuse a 0-row image -- but must still take part in the collectives that follow, so it returns an
+    empty int16 strip instead of raising while its peers wait in the all_gather."""
+    import torch
+    if out_rows <= 0:
+        return torch.empty((0, int(subL.shape[1])), dtype=torch.int16, device=subL.device)
+    return matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows)
 
 
 class StripContext:
@@ -196,7 +206,7 @@ class StripContext:
                 for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
                     self.subL[lo:hi].copy_(tl)
                     self.subR[lo:hi].copy_(tr)
-        strip = self.matcher._compute_device(self.subL, self.subR, out_row0=o0, out_rows=self.r1 - self.r0)
+        strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0)
         if not gather:
             return strip
         if self.world == 1 and not dist.is_initialized():

@@ -53,6 +53,31 @@ def test_remap_kernel_vs_oracle_and_host_path(env):
     assert np.array_equal(out.cpu().numpy(), _rigs._remap(small, mx, my))
 
 
+def test_remap_kernel_rounds_ties_up_like_opencv_fixed_point(env):
+    """(sum + 16384) >> 15 of cv2.remap's 8-bit bilinear path: fx = 16/32 between pixels 2 and 3 gives 3"""
+    ss, torch, rig = env
+    import ctypes
+    from oracle import rig_oracle
+    from simplestereo_amd import _native, _rigs
+    img = np.zeros((4, 6, 3), np.uint8)
+    img[:, :, 0] = [0, 2, 3, 7, 8, 255]
+    img[:, :, 1] = np.arange(6)[None, :] * 40
+    img[:, :, 2] = 255 - img[:, :, 0]
+    img[2:] //= 2
+    fy, fx = np.mgrid[0:32, 0:32]
+    mx = np.concatenate([(1 + fx / 32.0), np.full((1, 32), 1.5)], 0).astype(np.float32)
+    my = np.concatenate([(1 + fy / 32.0), np.zeros((1, 32))], 0).astype(np.float32)
+    out = torch.empty((33, 32, 3), dtype=torch.uint8, device="cuda")
+    ts, tmx, tmy = torch.from_numpy(img).cuda(), torch.from_numpy(mx).cuda(), torch.from_numpy(my).cuda()
+    _native.check(_native.lib().ssamd_remap_bgr_device(ts.data_ptr(), 4, 6, tmx.data_ptr(), tmy.data_ptr(), 33, 32, 1,
+                                                       out.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got[32, 0, 0] == 3                        # (2 + 3) / 2 = 2.5 -> 3, not 2
+    assert np.array_equal(got, rig_oracle.remap_bilinear(img, mx, my))
+    assert np.array_equal(got, _rigs._remap(img, mx, my))
+
+
 def test_reproject_kernel_vs_oracle_and_host_path(env):
     ss, torch, rig = env
     from oracle import rig_oracle

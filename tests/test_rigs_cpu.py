@@ -93,6 +93,51 @@ def test_remap_bilinear_on_linear_ramp_and_borders():
     assert near[5, 7] == u8[int(np.rint(mapy[5, 7])), int(np.rint(mapx[5, 7]))]
 
 
+def test_remap_uint8_ties_round_up_like_opencv_fixed_point():
+    """cv2.remap's 8-bit bilinear path ends in FixedPtCast: (sum + (1 << 14)) >> 15 with integer weights summing to
+    32768 (imgwarp.cpp), so a tie rounds UP: fx = 16/32 between pixels 2 and 3 gives 3 (half-to-even would give 2).
+    Host numpy path and the per-pixel oracle restatement must agree on every tie."""
+    from oracle import rig_oracle
+    img = np.zeros((4, 6, 3), np.uint8)
+    img[:, :, 0] = [0, 2, 3, 7, 8, 255]
+    img[:, :, 1] = np.arange(6)[None, :] * 40
+    img[:, :, 2] = 255 - img[:, :, 0]
+    img[2:] //= 2
+    mapx = np.array([[1.5, 2.5, 3.5, 0.5, 4.5, 5.5, -0.5]], np.float32)
+    mapy = np.zeros_like(mapx)
+    out = _rigs._remap(img, mapx, mapy)
+    assert out[0, 0, 0] == 3            # (2 + 3) / 2 = 2.5 -> 3
+    assert out[0, 1, 0] == 5            # (3 + 7) / 2 = 5
+    assert out[0, 2, 0] == 8            # (7 + 8) / 2 = 7.5 -> 8
+    assert out[0, 3, 0] == 1            # (0 + 2) / 2 = 1
+    assert out[0, 4, 0] == 132          # (8 + 255) / 2 = 131.5 -> 132
+    assert out[0, 5, 0] == 128          # (255 + border 0) / 2 = 127.5 -> 128
+    assert out[0, 6, 0] == 0            # (border 0 + 0) / 2
+    assert np.array_equal(out, rig_oracle.remap_bilinear(img, mapx, mapy))
+    # every 1/32 fraction in both directions, including all quarter-way ties
+    fy, fx = np.mgrid[0:32, 0:32]
+    mx = (1 + fx / 32.0).astype(np.float32)
+    my = (1 + fy / 32.0).astype(np.float32)
+    got = _rigs._remap(img, mx, my)
+    assert np.array_equal(got, rig_oracle.remap_bilinear(img, mx, my))
+    a, b, c, d = (int(img[1, 1, 0]), int(img[1, 2, 0]), int(img[2, 1, 0]), int(img[2, 2, 0]))
+    want = ((32 - fy) * (32 - fx) * a + (32 - fy) * fx * b + fy * (32 - fx) * c + fy * fx * d + 512) >> 10
+    assert np.array_equal(got[:, :, 0], want)
+
+
+def test_undistort_points_follows_opencv_default_iteration_count():
+    """cv2.undistortPoints stops after 5 fixed-point iterations by default; the corner positions that feed the
+    fitting matrix (reference rectification.py:125-156) are those of the 5th iterate"""
+    K = np.array([[800.0, 0, 320], [0, 800, 240], [0, 0, 1]])
+    dist = np.array([-0.3, 0.12, 0.001, -0.002, 0.0])
+    pts = np.array([[0.0, 0.0], [639, 0], [639, 479], [0, 479]])
+    five = _rigs._undistort_points(pts, K, dist)
+    assert np.array_equal(five, _rigs._undistort_points(pts, K, dist, iterations=5))
+    conv = _rigs._undistort_points(pts, K, dist, iterations=200)
+    assert not np.array_equal(five, conv)                    # the default is not the converged solution ...
+    assert np.abs(five - conv).max() < 5e-3                  # ... but within 5e-3 (normalised units) of it here
+
+
 def test_rectify_images_feeds_matcher_shapes():
     rig = ss.RectifiedStereoRig.fromFile(RIGRECT)
     rig.computeRectificationMaps(destDims=(160, 90))
