@@ -70,7 +70,11 @@ def importPLY(filename, *properties):
         for line in f:
             if line.rstrip().lower() == "end_header":
                 break
-        data = np.loadtxt(f, dtype=float, ndmin=2)
+        body = f.read()
+    if not body.strip():
+        return np.zeros((0,), dtype=float)
+    import io
+    data = np.loadtxt(io.StringIO(body), dtype=float, ndmin=2)
     return np.ascontiguousarray(data[:, list(properties)]) if data.size else np.zeros((0,), dtype=float)
 
 

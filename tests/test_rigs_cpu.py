@@ -188,6 +188,33 @@ def test_ply_round_trip_and_reference_header(tmp_path):
     assert ss.points.importPLY(str(h)).shape == (20, 3)
 
 
+@pytest.mark.parametrize("name,key,prec", [("ply_none_p6.ply", None, 6), ("ply_bgr_p4.ply", "bgr", 4),
+                                           ("ply_gray_i64_p3.ply", "gray_i64", 3), ("ply_gray_u8_p6.ply", "gray_u8", 6),
+                                           ("ply_gray_f32_p2.ply", "gray_f32", 2)])
+def test_export_ply_equals_the_files_the_reference_writes(tmp_path, name, key, prec):
+    """pinned: tests/golden/ply_*.ply were written by the unmodified reference exportPLY (points.py:10-80, via
+    tests/golden/make_golden_ply.py) from the inputs in ply_cases.npz -- our writer must produce the same bytes
+    (header, column order, int64-only `int intensity`, the `{:{p}f}` float field), and our reader the same values"""
+    G = os.path.dirname(RIGRECT)
+    z = np.load(os.path.join(G, "ply_cases.npz"))
+    flat = z["pts"].reshape(-1, 3)
+    img = None if key is None else z[key]
+    out = tmp_path / name
+    ss.points.exportPLY(flat, str(out), img, precision=prec)
+    assert open(out, "rb").read() == open(os.path.join(G, name), "rb").read()
+    back = ss.points.importPLY(os.path.join(G, name))
+    assert back.shape == (12, 3) and np.allclose(back, flat, atol=0.5 * 10.0 ** -prec)
+    if key == "bgr":
+        rgb = ss.points.importPLY(os.path.join(G, name), 3, 4, 5)
+        assert np.array_equal(rgb.astype(np.uint8), z["bgr"].reshape(-1, 3)[:, ::-1])
+
+
+def test_import_ply_of_an_empty_cloud_has_the_reference_shape(tmp_path):
+    f = tmp_path / "e.ply"
+    ss.points.exportPLY(np.zeros((0, 3)), str(f))
+    assert ss.points.importPLY(str(f)).shape == (0,)        # np.asarray([], dtype=float), reference points.py:121
+
+
 def test_adimensional_points_geometry():
     d = np.full((6, 8), 2, np.int16)
     p = ss.points.getAdimensional3DPoints(d)
