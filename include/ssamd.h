@@ -146,6 +146,16 @@ int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int wi
                     int winSize, int maxDisparity, int minDisparity,
                     double gammaC, double gammaP, float *costs, int device);
 
+/* The two raw winner-take-all results of the consistent mode BEFORE the left-right check and the occlusion
+ * filling (_passive.cpp:188 and 248-250): left_disparity[y][x] = x - dBest of the left-referenced pass,
+ * right_match[y][xr] = dBest of the right-referenced pass, i.e. the LEFT column the right pixel xr selects (0 when
+ * its candidate loop is empty).  int16 [height][width] host buffers, synchronous.  Lets a test check the argmins
+ * against the reference's fp64 costs and the finalisation kernel against a literal restatement separately. */
+int ssamd_asw_argmins(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                      int winSize, int maxDisparity, int minDisparity,
+                      double gammaC, double gammaP,
+                      int16_t *left_disparity, int16_t *right_match, int device);
+
 /* CIELab conversion used by ASW (replaces ColorConversion::ImageFromBGR2Lab,
  * headers/colorconversion.hpp:81-86); float32 [height][width][3]. Host buffers. */
 int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device);

@@ -58,6 +58,8 @@ def lib():
     L.ssamd_asw_alternate_device.argtypes = [P, P, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_costs.restype = I
     L.ssamd_asw_costs.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
+    L.ssamd_asw_argmins.restype = I
+    L.ssamd_asw_argmins.argtypes = [P, P, I, I, I, I, I, D, D, P, P, I]
     L.ssamd_bgr2lab.restype = I
     L.ssamd_bgr2lab.argtypes = [P, I, I, P, I]
     L.ssamd_remap_bgr_device.restype = I

@@ -517,15 +517,17 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
 
 // K2a: decode left keys (non-consistent mode).  disparity = d of the best key, or x
 // when the candidate loop was empty (dBest stays 0, _passive.cpp:54,98).
+// right_keys != 0: the keys are right-referenced (low word = best LEFT column of the right pixel, 0 when its
+// candidate loop was empty, _passive.cpp:209) -- only used by the verification dump ssamd_asw_argmins.
 __global__ __launch_bounds__(256) void wta_decode_kernel(const u64 *__restrict__ keyL, int16_t *__restrict__ disp,
-                                                         int rows, int W)
+                                                         int rows, int W, int right_keys)
 {
     const long long n = (long long)rows * W;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; idx < n; idx += stride) {
         const u64 k = keyL[idx];
-        const int x = (int)(idx % W);
+        const int x = right_keys ? 0 : (int)(idx % W);
         disp[idx] = (k == KEY_NONE) ? (int16_t)x : (int16_t)(uint32_t)k;
     }
 }

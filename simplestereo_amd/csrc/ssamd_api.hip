@@ -519,11 +519,17 @@ int launch_lab_records(Ctx &c, const uint8_t *d_img, PixRec *rec, int W, int r0,
     return SSAMD_OK;
 }
 
-int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_disp, hipStream_t s)
+int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_disp, hipStream_t s,
+                    int16_t *d_raw_right = nullptr)
 {
     if (rows <= 0) return SSAMD_OK;
     Timed t(c, s, slot);
-    if (lrcheck) {
+    if (d_raw_right) {          // verification dump: both raw argmins instead of the left-right check and filling
+        const long long n = (long long)rows * W;
+        const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyL.ptr, d_disp, rows, W, 0);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyR.ptr, d_raw_right, rows, W, 1);
+    } else if (lrcheck) {
         const size_t lds = (((size_t)W * 2 + 15) & ~(size_t)15) + W;      // up to 96 KiB at the 32767-column limit
         int rc = grant_dyn_lds(c, (const void *)lr_check_fill_kernel, (int)lds);
         if (rc) return rc;
@@ -532,7 +538,7 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
     } else {
         const long long n = (long long)rows * W;
         const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 8);
-        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyL.ptr, d_disp, rows, W);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyL.ptr, d_disp, rows, W, 0);
     }
     HIP_TRY(hipGetLastError());
     return SSAMD_OK;
@@ -540,7 +546,7 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
 
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
-                    float *d_costs, hipStream_t s, bool alternate = false)
+                    float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr)
 {
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
@@ -653,7 +659,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         }
     }
     const bool direct = is_direct(a.g);
-    if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s))) return rc;
+    if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
     if (alternate && rows > 1) {
         // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
         // empty disparity range the decode already wrote x everywhere and the fill reproduces it.
@@ -877,6 +883,7 @@ struct HostJob {
     int16_t *disparity;            // full-image output [H][W]
     // ASW
     double gammaC, gammaP; int consistent; float *costs; bool alternate;
+    int16_t *raw_right;            // verification dump (ssamd_asw_argmins): raw right-referenced matches, full image
     // GSW
     int gamma; float fMax; int iterations;
 };
@@ -892,14 +899,18 @@ int asw_host_rows(const HostJob &j, int device)
     if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
     const size_t ncost = j.costs ? nout * (size_t)std::max(1, j.maxD - j.minD + 1) : 0;
     if (j.costs && (rc = c->costs.reserve(ncost * 4))) return rc;
+    if (j.raw_right && (rc = c->lab.reserve(nout * 2))) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(c->imgL.ptr, j.img1 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->imgR.ptr, j.img2 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
     if (j.costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
     rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
                          j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr,
-                         j.costs ? (float *)c->costs.ptr : nullptr, s, j.alternate);
+                         j.costs ? (float *)c->costs.ptr : nullptr, s, j.alternate,
+                         j.raw_right ? (int16_t *)c->lab.ptr : nullptr);
     if (rc) return rc;
+    if (j.raw_right)
+        HIP_TRY(hipMemcpyAsync(j.raw_right + (size_t)j.o0 * j.W, c->lab.ptr, nout * 2, hipMemcpyDeviceToHost, s));
     if (j.disparity)
         HIP_TRY(hipMemcpyAsync(j.disparity + (size_t)j.o0 * j.W, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
     if (j.costs) HIP_TRY(hipMemcpyAsync(j.costs, c->costs.ptr, ncost * 4, hipMemcpyDeviceToHost, s));
@@ -1094,6 +1105,18 @@ int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int wi
     if (maxDisparity < minDisparity) return fail(SSAMD_EINVAL, "empty disparity range");
     return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, nullptr,
                                  costs, false), device);
+}
+
+int ssamd_asw_argmins(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                      int minDisparity, double gammaC, double gammaP, int16_t *left_disparity, int16_t *right_match,
+                      int device)
+{
+    if (!img1 || !img2 || !left_disparity || !right_match) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (maxDisparity < minDisparity) return fail(SSAMD_EINVAL, "empty disparity range");
+    HostJob j = asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 1, left_disparity,
+                        nullptr, false);
+    j.raw_right = right_match;
+    return asw_host_rows(j, device);
 }
 
 int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device)

@@ -9,6 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))      # shared test helpers (tests/_lr_helpers.py)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -4,6 +4,8 @@ multiple of the register tile, single-row / single-column images, empty candidat
 import numpy as np
 import pytest
 
+from _lr_helpers import lr_check_fill_literal as _lr_check_fill_literal, oracle_argmins as _oracle_argmins
+
 pytestmark = pytest.mark.gpu
 
 
@@ -64,17 +66,59 @@ def test_asw_fuzz_vs_oracle(case, ss):
     assert bad <= max(1, 0.005 * H * W), (case, bad)
 
 
+def _gpu_argmins(a, b, p):
+    from simplestereo_amd import _native
+    H, W = a.shape[:2]
+    left, right = np.empty((H, W), np.int16), np.empty((H, W), np.int16)
+    _native.check(_native.lib().ssamd_asw_argmins(a.ctypes.data, b.ctypes.data, H, W, p["winSize"], p["maxDisparity"],
+                                                  p["minDisparity"], p["gammaC"], p["gammaP"], left.ctypes.data,
+                                                  right.ctypes.data, -1))
+    return left, right
+
+
 @pytest.mark.parametrize("case", [c for c in _cases(40, 4048) if c[0] >= 16 and c[1] >= 32][:14])
 def test_asw_consistent_fuzz_vs_oracle(case, ss):
-    """LR check + fill amplify a flipped argmin into a run of pixels, so the bar is on the fraction"""
+    """consistent=True, decomposed so that the north_star bar (>= 99.5 % within 1 level) can be held where it is
+    meaningful.  The left-right check + filling amplify ONE flipped argmin into a run of pixels, and an argmin can
+    only flip where the reference's own choice is rounding noise (two candidates whose fp64 costs agree to 1e-6
+    relative -- in practice fully saturated candidates, all taps at TAD = 40).  So:
+      (1) the finalisation kernel equals a literal restatement of _passive.cpp:250-285 applied to the GPU's own two
+          raw argmin maps, bit for bit;
+      (2) every raw argmin (left- and right-referenced) is the oracle's, or within 1 level of it, or a numerical tie
+          of the oracle's fp64 costs, for all but 0.5 % of the pixels;
+      (3) over the rows that contain no such tie-flipped argmin the final map is within 1 level of the oracle's
+          consistent map on >= 99.5 % of the pixels."""
     from oracle import oracle
     H, W, win, minD, maxD, _, seed = case
     a, b = _shifted_pair(H, W, minD, maxD, seed)
-    p = dict(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=float(3 + seed % 9), gammaP=float(5 + seed % 20), consistent=True)
-    d = ss.passive.StereoASW(**p).compute(a, b)
-    ref = oracle.asw(a, b, **p)
-    within1 = float(np.mean(np.abs(d.astype(np.int32) - ref) <= 1))
-    assert within1 >= 0.98, (case, within1)
+    p = dict(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=float(3 + seed % 9), gammaP=float(5 + seed % 20))
+    d = ss.passive.StereoASW(consistent=True, **p).compute(a, b)
+    gl, gr = _gpu_argmins(a, b, p)
+    assert np.array_equal(gl, ss.passive.StereoASW(**p).compute(a, b))             # the left argmin IS the plain map
+    assert np.array_equal(d, _lr_check_fill_literal(gl, gr)), case                   # (1)
+    ref = oracle.asw(a, b, consistent=True, **p)
+    _, cref = oracle.asw(a, b, return_costs=True, **p)
+    ol, orr = _oracle_argmins(cref, minD, maxD)
+    bad = 0
+    tie_rows = np.zeros(H, bool)
+
+    def tie(c1, c2):
+        return np.isfinite(c1) and np.isfinite(c2) and abs(c1 - c2) <= 1e-6 * max(1.0, abs(c2))
+    for y, x in np.argwhere(gl.astype(np.int32) != ol):
+        t = tie(cref[y, x, gl[y, x] - minD], cref[y, x, ol[y, x] - minD])
+        tie_rows[y] |= t
+        bad += (abs(int(gl[y, x]) - int(ol[y, x])) > 1) and not t
+    for y, x in np.argwhere(gr.astype(np.int32) != orr):
+        g, o = int(gr[y, x]), int(orr[y, x])
+        inside = 0 <= g - x - minD < cref.shape[2] and 0 <= o - x - minD < cref.shape[2]
+        t = inside and tie(cref[y, g, g - x - minD], cref[y, o, o - x - minD])
+        tie_rows[y] |= t
+        bad += (abs(g - o) > 1) and not t
+    assert bad <= max(1, 0.005 * 2 * H * W), (case, bad)                             # (2)
+    keep = ~tie_rows
+    if keep.any():
+        within1 = float(np.mean(np.abs(d[keep].astype(np.int32) - ref[keep]) <= 1))
+        assert within1 >= 0.995, (case, within1, int(keep.sum()), H)                 # (3)
 
 
 @pytest.mark.parametrize("case", _cases(30, 77))

@@ -1,0 +1,73 @@
+"""GPU tier: the HEADLINE launch geometries against the unmodified reference.
+
+tests/golden/wide_cases.npz holds maps the reference extension (oracle/_ref, _passive.cpp) computed on full-width
+strips cropped from the synthetic frames of BASELINE configs 3, 4 and 5 (tests/golden/make_golden_wide.py): 1920
+columns / D 0..192 / win 35 (plain and consistent), 1920 / D 0..16 (the class-default range), 4096 / D 0..256, and GSW
+1920 / D 0..192 / win 11.  These are the workgroup tiles, tap-column chunkings and key paths the bench line runs
+(120 x 196 tiles, 16-column chunks, two e tiles; GSW two-row strips), which the small goldens never reach.
+
+Bars: ASW (fp32 kernels vs the fp64 reference) >= 99.5 % of all pixels within 1 level (north_star) and, tighter,
+>= 99 % identical; GSW: 0 mismatching pixels."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def wide():
+    maps = np.load(os.path.join(G, "wide_cases.npz"))
+    meta = json.load(open(os.path.join(G, "wide_cases.json")))
+    return maps, meta
+
+
+_frames = {}
+
+
+def _inputs(m):
+    from simplestereo_amd.synth import make_pair
+    H, W, maxD, seed = m["frame"]
+    if (H, W, maxD, seed) not in _frames:
+        _frames.clear()                                   # one frame at a time: the 4K pair is 2 x 26 MB
+        _frames[(H, W, maxD, seed)] = make_pair(H, W, maxD, seed)[:2]
+    L, R = _frames[(H, W, maxD, seed)]
+    r0, rows = m["row0"], m["rows"]
+    return np.ascontiguousarray(L[r0:r0 + rows]), np.ascontiguousarray(R[r0:r0 + rows])
+
+
+@pytest.mark.parametrize("cid", ["W3a", "W3b", "W3c", "W5a"])
+def test_asw_headline_geometry_vs_reference(cid, wide):
+    import simplestereo_amd as ss
+    maps, meta = wide
+    m = meta[cid]
+    a, b = _inputs(m)
+    p = {k: v for k, v in m["params"].items() if k != "algo"}
+    d = ss.passive.StereoASW(**p).compute(a, b)
+    ref = maps[cid]
+    assert d.shape == ref.shape and d.dtype == np.int16
+    diff = np.abs(d.astype(np.int32) - ref.astype(np.int32))
+    within1, exact = float(np.mean(diff <= 1)), float(np.mean(diff == 0))
+    print("%s %dx%d D %d..%d consistent=%s: exact %.4f %%, within-1 %.4f %%" %
+          (cid, a.shape[1], a.shape[0], p["minDisparity"], p["maxDisparity"], p["consistent"], 100 * exact, 100 * within1))
+    assert within1 >= 0.995, (cid, within1)
+    assert exact >= 0.99, (cid, exact)
+    # the resident-tensor entry point and a two-strip cut of the same sub-image give the same map
+    import torch
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    assert np.array_equal(ss.passive.StereoASW(**p).compute(ta, tb).cpu().numpy(), d)
+
+
+@pytest.mark.parametrize("cid", ["W4a", "W4b"])
+def test_gsw_headline_geometry_vs_reference_bit_exact(cid, wide):
+    import simplestereo_amd as ss
+    maps, meta = wide
+    m = meta[cid]
+    a, b = _inputs(m)
+    p = {k: v for k, v in m["params"].items() if k != "algo"}
+    d = ss.passive.StereoGSW(**p).compute(a, b)
+    assert np.array_equal(d, maps[cid]), (cid, int(np.count_nonzero(d != maps[cid])))

@@ -83,6 +83,43 @@ def test_oracle_cost_dump_consistent_with_wta(golden_inputs):
             assert ok.sum() == min(6, x) - 1 + 1
 
 
+@pytest.mark.parametrize("inp,p", [("crop", dict(winSize=7, maxDisparity=6, minDisparity=1)),
+                                   ("synth_64x96", dict(winSize=9, maxDisparity=24, minDisparity=2, gammaC=7.5, gammaP=36)),
+                                   ("crop", dict(winSize=5, maxDisparity=60, minDisparity=0))])
+def test_consistent_map_is_lr_check_and_fill_of_the_two_argmins(inp, p, golden_inputs):
+    """the helpers the GPU tier uses to take the consistent mode apart (tests/_lr_helpers.py): both winner-take-all
+    scans recomputed from the oracle's fp64 cost dump (the right-referenced cost of (xr, xl) is the left-referenced
+    cost of (xl, xl - xr)), pushed through a literal restatement of _passive.cpp:250-285, give the oracle's -- i.e.
+    the reference's -- consistent map bit for bit"""
+    from _lr_helpers import lr_check_fill_literal, oracle_argmins
+    a, b = golden_inputs(inp)
+    plain, costs = oracle.asw(a, b, return_costs=True, **p)
+    left, right = oracle_argmins(costs, p["minDisparity"], p["maxDisparity"])
+    assert np.array_equal(left, plain)
+    assert np.array_equal(lr_check_fill_literal(left, right), oracle.asw(a, b, consistent=True, **p))
+
+
+@pytest.mark.parametrize("cid", ["W3c", "W4a"])
+def test_oracle_on_headline_width_strips(cid):
+    """the C restatement (hoisted / closed-form modes) against the reference's maps of full-width strips of the
+    config-3 / config-4 frames (tests/golden/wide_cases.npz): 1920 columns, the class-default range D 0..16 win 35
+    for ASW and D 0..192 win 11 for GSW -- bit-exact.  (The D 0..192 / 0..256 ASW strips are checked on the GPU tier
+    only: the oracle needs minutes for them.)"""
+    import json
+    import os
+    from simplestereo_amd.synth import make_pair
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    m = json.load(open(os.path.join(G, "wide_cases.json")))[cid]
+    want = np.load(os.path.join(G, "wide_cases.npz"))[cid]
+    H, W, maxD, seed = m["frame"]
+    L, R, _ = make_pair(H, W, maxD, seed)
+    a = np.ascontiguousarray(L[m["row0"]:m["row0"] + m["rows"]])
+    b = np.ascontiguousarray(R[m["row0"]:m["row0"] + m["rows"]])
+    p = {k: v for k, v in m["params"].items() if k != "algo"}
+    got = oracle.asw(a, b, hoist=True, **p) if m["params"]["algo"] == "asw" else oracle.gsw(a, b, closed=True, **p)
+    assert np.array_equal(got, want)
+
+
 def test_oracle_lab_known_values():
     """colorconversion.hpp:18-70 on a few bytes with textbook Lab values"""
     px = np.array([[[0, 0, 0], [255, 255, 255], [0, 0, 255], [255, 0, 0]]], np.uint8)   # BGR
