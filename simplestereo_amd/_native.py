@@ -7,7 +7,10 @@ visible, the calls fail loudly.
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB_PATH
+
+# experiments only (tools/build_variants.sh): load another build of the same library
+LIB_PATH = os.environ.get("SSAMD_LIB") or _DEFAULT_LIB_PATH
 
 K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_ASW_ALT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 

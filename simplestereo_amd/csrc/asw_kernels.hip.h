@@ -52,6 +52,9 @@ struct AswGeom {
     int e2;                      // 1: two e tiles (rows alternate): no barrier between the last chunk of a window row and
                                  //    the e / weight build of the next one (chunked form with >= 2 chunks only)
     int e_bytes;                 // size of one e tile
+    int pipe;                    // 1: asw_aggregate_pipe_kernel (asw_pipe_kernel.hip.h): phase-shifted build / aggregation
+    int NC, JCmax;               //    chunks per window row (tail shorter than 8 merged into the last) and rows per weight buffer
+    int dephase;                 //    1: waves 0-3 build before they aggregate, the others after (0: all after)
     int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
 };

@@ -1,0 +1,393 @@
+// K1p: the phase-shifted ("pipelined") form of the ASW aggregation kernel (gfx950).
+//
+// Same algebra, same per-thread 8 x 4 register tile, same tap order and therefore bit-identical sums as
+// asw_aggregate_kernel (asw_kernels.hip.h); what changes is WHEN each wave does its build work.
+//
+// asw_aggregate_kernel<CHUNKED> runs every wave in lockstep:  build(c) | barrier | aggregate(c) | build(c+1) | barrier ...
+// The build work (support weights: LDS read -> 3 sub, 3 fma -> v_sqrt -> v_exp -> LDS write; e tiles; pixel staging)
+// is a dependent chain of ~200 cycles with little to overlap it when all twelve waves of the CU are in it at the same
+// time: measured, the build phases alone cost 13.8 ms of the 44.5 ms of a 1080p / D 0..192 / win 35 frame although
+// their VALU work is worth ~4 ms.
+//
+// Here the build for the NEXT chunk only touches buffers the current chunk does not read (second weight buffer,
+// second e tile, other pixel-staging buffer), so a wave may do it at any point between the chunk's two barriers.
+// The twelve waves of a workgroup sit three per SIMD (waves w, w+4, w+8 share a SIMD) and are given three different
+// orders, one per SIMD-mate:
+//     waves 0-3  : build(next) , aggregate(chunk)
+//     waves 4-11 : aggregate(chunk) , build(next)
+// so that on every SIMD the first wave's latency-bound build chains are covered by the FMA streams of its two
+// mates, and theirs by the first wave's (it starts aggregating later and is still at it when they build).
+// One barrier per chunk, as before.
+//
+// Chunks: tap columns [c*JC, (c+1)*JC) with JC = 8 or 16 and a tail shorter than 8 merged into the last chunk
+// (win 35, JC 8: 8, 8, 8, 11), so that the work hidden under a chunk and the chunk itself stay comparable.
+// build(next) of chunk c of window row i is
+//     c == 0        : stage the pixels of image row i+1 (global -> LDS) + weights of chunk 1
+//     0 < c < NC-1  : weights of chunk c+1                              + a share of the e tile of row i+1
+//     c == NC-1     : weights of chunk 0 of row i+1                     + the last share of that e tile
+// Needs NC >= 2 chunks (the pixels staged under chunk 0 are first read under chunk 1) and two e tiles.
+//
+// LDS layout ("plain rows", AswGeom::pipe): the lanes of a wave run along the DISPARITY groups of one column group
+// (thread = xg * DG + dg), not along x as in asw_aggregate_kernel.  The right-weight blocks a thread reads start at
+// float 8 xg - 4 dg + Dc - 4 of a weight row, so consecutive lanes read consecutive 16-byte blocks of a PLAIN row
+// (the hardware serves a ds_read_b128 in groups of 16 lanes whose 16-byte slots must differ mod 16: any run of 32
+// consecutive blocks does); the left-weight blocks are the same for all lanes of a column group (broadcast); the e
+// dwords of a lane group are consecutive in a plain e row.  rocprofv3 on the x-fastest layout with its 15-wide
+// thread rows: 21 bank-conflict cycles per 26-cycle aggregation step (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.37, LDS 55 % busy); see profiles/r02_*.  It also needs one running pointer per operand instead of three for
+// wR and no swizzle arithmetic.
+#pragma once
+#include "asw_kernels.hip.h"
+
+namespace ssamd {
+
+template <bool WITH_COSTS>
+__global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(const AswArgs A)
+{
+    constexpr int RX = ASW_RX;
+    constexpr int NWR = asw_nwr(RX);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AswGeom &g = A.g;
+    float *const wL = reinterpret_cast<float *>(smem + g.off_wL);
+    float *const wR = reinterpret_cast<float *>(smem + g.off_wR);
+    unsigned char *const eT0 = reinterpret_cast<unsigned char *>(smem + g.off_e);
+    float4 *const labL = reinterpret_cast<float4 *>(smem + g.off_labL);
+    float4 *const labR = reinterpret_cast<float4 *>(smem + g.off_labR);
+    uint32_t *const bgrL = reinterpret_cast<uint32_t *>(smem + g.off_bgrL);
+    uint32_t *const bgrR = reinterpret_cast<uint32_t *>(smem + g.off_bgrR);
+    u64 *const bestL = reinterpret_cast<u64 *>(smem + g.off_bestL);
+    u64 *const bestR = reinterpret_cast<u64 *>(smem + g.off_bestR);
+    float4 *const cenLab = reinterpret_cast<float4 *>(smem + g.off_cen);
+    float *const proxS = reinterpret_cast<float *>(smem + g.off_prox);
+
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int W = A.W, win = A.win, p = A.pad;
+    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nR = g.nR, nRc = g.nRc, SR = g.SR, Se = g.Se;
+    const int JC = g.JC, NC = g.NC;
+    int bx = blockIdx.x;                          // XCD-aware tile order, see asw_aggregate_kernel
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int x0 = bx * Tx;
+    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int dlo = A.minD + blockIdx.z * Dc;
+    const int dhi = dlo + Dc - 1;
+    if (min(x0 + Tx - 1, W - 1) - dlo < 0) {      // no candidate the reference evaluates in this tile
+        if (A.disp)
+            for (int k = threadIdx.x; k < Tx && x0 + k < W; k += blockDim.x)
+                A.disp[(size_t)(y - A.row0) * W + x0 + k] = (int16_t)(x0 + k);
+        return;
+    }
+    const int segL_lo = x0 - p, xrc_lo = x0 - dhi, segR_lo = xrc_lo - p;
+    // which of the two orders this wave follows (0: build first): wave-uniform, kept in a scalar register
+    const int phase = g.dephase ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 1;
+
+    float accN[RX][ASW_RD], accS[RX][ASW_RD];
+#pragma unroll
+    for (int a = 0; a < RX; ++a)
+#pragma unroll
+        for (int b = 0; b < ASW_RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
+
+    for (int k = tid; k < Tx; k += nthr) bestL[k] = KEY_NONE;
+    for (int k = tid; k <= nRc; k += nthr) bestR[k] = KEY_NONE;
+    for (int c = tid; c < Tx + nRc; c += nthr) {   // window centres (row y): left columns x0.., right columns xrc_lo..
+        const bool isL = c < Tx;
+        const int ccol = isL ? x0 + c : xrc_lo + (c - Tx);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ccol < (unsigned)W) {
+            const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+            v = make_float4(q.L, q.a, q.b, 1.f);
+        }
+        cenLab[c] = v;
+    }
+
+    const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
+
+    // ---- build pieces.  Every thread index they use is re-derived from an opaque copy of threadIdx.x so that
+    //      nothing of a build stays live across the aggregation (168-VGPR budget, no scratch).
+    // pixels (and the proximity row) of window row i -> staging buffer i & 1
+    auto stage_row = [&](int i) {
+        int tids = threadIdx.x;
+        asm volatile("" : "+v"(tids));
+        const int buf = i & 1, r = y - p + i;
+        for (int k = tids; k < win; k += nthr) proxS[buf * win + k] = A.prox[i * win + k];
+        const PixRec *const rowL = A.recL + (size_t)r * W;
+        const PixRec *const rowR = A.recR + (size_t)r * W;
+        for (int k = tids; k < nL + nR; k += nthr) {
+            const bool isL = k < nL;
+            const int idx = isL ? k : k - nL;
+            const int col = (isL ? segL_lo : segR_lo) + idx;
+            PixRec v;
+            v.L = v.a = v.b = 0.f;
+            v.bgrx = 0u;
+            if ((unsigned)col < (unsigned)W) v = (isL ? rowL : rowR)[col];
+            (isL ? labL + buf * nL : labR + buf * nR)[idx] = make_float4(v.L, v.a, v.b, 0.f);
+            (isL ? bgrL + buf * nL : bgrR + buf * nR)[idx] = v.bgrx;
+        }
+    };
+    // tasks [t_lo, t_hi) of the e tile of window row i (task = tap column ul x pair of disparity groups, flat index
+    // sp * nL + ul): e[ul][d] = min(40, |dB|+|dG|+|dR|) (_passive.cpp:77-79) from the staged bytes
+    auto build_e = [&](int i, int t_lo, int t_hi) {
+        int tidb = threadIdx.x;
+        asm volatile("" : "+v"(tidb));
+        unsigned char *const eT = eT0 + (i & 1) * g.e_bytes;
+        const uint32_t *const bgrLc = bgrL + (i & 1) * nL, *const bgrRc = bgrR + (i & 1) * nR;
+        const int e_q = nthr / nL, e_r = nthr - e_q * nL;
+        int t = t_lo + tidb;
+        int sp = t / nL, ul = t - sp * nL;
+        while (t < t_hi) {
+            const uint32_t lp = bgrLc[ul];
+            const uint32_t *const rp = bgrRc + (ul + (Dc - 1) - 8 * sp);   // R[u-d] for d = dlo + 8*sp
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo |= min(__builtin_amdgcn_sad_u8(lp, rp[-k], 0u), 40u) << (8 * k);
+                hi |= min(__builtin_amdgcn_sad_u8(lp, rp[-4 - k], 0u), 40u) << (8 * k);
+            }
+            uint32_t *const dst = reinterpret_cast<uint32_t *>(eT + ul * Se) + 2 * sp;
+            dst[0] = lo;
+            if (2 * sp + 1 < g.DG) dst[1] = hi;
+            t += nthr; ul += e_r; sp += e_q;
+            if (ul >= nL) { ul -= nL; ++sp; }
+        }
+    };
+    // support weights of window row i, tap columns [jb, je), into weight buffer rows rb.. (_passive.cpp:47-50, 71-74;
+    // exp(-dist/gammaC) = exp2(dist*kC)).  One thread per window centre, all columns of the chunk: batches of ASW_WB
+    // independent chains walking running pointers; taps or centres outside the image get weight 0 through a mask.
+    auto build_weights = [&](int i, int jb, int je, int rb) {
+        int tidw = threadIdx.x;
+        asm volatile("" : "+v"(tidw));
+        const float4 *const labLc = labL + (i & 1) * nL, *const labRc = labR + (i & 1) * nR;
+        const float *const prow = proxS + (i & 1) * win;
+        const int ncen = Tx + nRc;
+        // tasks: one centre per thread with all columns of the chunk while whole rounds of nthr centres last; the
+        // centres left over (fewer than nthr) are cut into column segments so that the last round is spread over
+        // the threads instead of leaving most of them idle behind a few (tiles with more centres than threads)
+        const int full = ncen / nthr * nthr, rest = ncen - full;
+        int slen = je - jb, nseg = 1;
+        if (rest > 0 && full > 0) {
+            slen = max(ASW_WB, (je - jb + nthr / rest - 1) / (nthr / rest));
+            slen = (slen + ASW_WB - 1) / ASW_WB * ASW_WB;
+            nseg = (je - jb + slen - 1) / slen;
+        }
+        const int ntasks = full + rest * nseg;
+        for (int t = tidw; t < ntasks; t += nthr) {
+            int c = t, jb_t = jb, je_t = je;
+            if (t >= full && nseg > 1) {
+                const int q = t - full, sgm = q / rest;
+                c = full + q - sgm * rest;
+                jb_t = jb + sgm * slen;
+                je_t = min(je, jb_t + slen);
+            }
+            const bool isL = c < Tx;
+            const int cc = isL ? c : c - Tx;
+            const float4 cen = cenLab[c];
+            const float4 *const seg = (isL ? labLc : labRc) + cc;
+            const int stride = isL ? g.SL : SR;
+            float *const wout = (isL ? wL : wR) + cc + (rb - jb) * stride;
+            const int col0 = (isL ? x0 : xrc_lo) + cc - p;
+            const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
+            int j = jb_t;
+            const float4 *sp = seg + j;
+            const float *pp = prow + j;
+            float *wp = wout + j * stride;
+            int col = col0 + j;
+            const int stride4 = ASW_WB * stride;
+            for (; j + ASW_WB <= je_t; j += ASW_WB, sp += ASW_WB, pp += ASW_WB, wp += stride4, col += ASW_WB) {
+                float4 tp[ASW_WB];
+                float pr[ASW_WB], wv[ASW_WB];
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) { tp[u] = sp[u]; pr[u] = pp[u]; }
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) {
+                    asm volatile("" ::"v"(tp[u].w));     // keeps the read a ds_read_b128 (4 LDS cycles; the 12-byte form takes 8)
+                    const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                    wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                }
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) {
+                    const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
+                    wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                }
+            }
+            if (j < je_t) {
+                float4 tp[ASW_WB];
+                float pr[ASW_WB], wv[ASW_WB];
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) {
+                    const int jj = min(j + u, je_t - 1);
+                    tp[u] = seg[jj];
+                    pr[u] = prow[jj];
+                }
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) {
+                    asm volatile("" ::"v"(tp[u].w));
+                    const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                    wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                }
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
+                    const int jj = min(j + u, je_t - 1);
+                    const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
+                    wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                }
+            }
+        }
+    };
+    auto chunk_end = [&](int c) { return c == NC - 1 ? win : (c + 1) * JC; };
+    const int nE = nL * ((g.DG + 1) >> 1);             // tasks of one e tile
+    // everything chunk c of window row i can hide: see the file header.  cb = weight buffer chunk c reads.
+    // (SSAMD_ABLATE_*: phase-ablation builds of tools/build_variants.sh, never defined in the product)
+    auto build_next = [&](int i, int c, int cb) {
+        const bool more_rows = i + 1 < i_hi;
+#ifndef SSAMD_ABLATE_STAGE
+        if (c == 0 && more_rows) stage_row(i + 1);
+#endif
+#ifndef SSAMD_ABLATE_WEIGHTS
+        if (c + 1 < NC) build_weights(i, (c + 1) * JC, chunk_end(c + 1), (cb ^ 1) * g.JCmax);
+        else if (more_rows) build_weights(i + 1, 0, chunk_end(0), (cb ^ 1) * g.JCmax);
+#endif
+#ifndef SSAMD_ABLATE_E
+        if (c >= 1 && more_rows) build_e(i + 1, (int)((long long)nE * (c - 1) / (NC - 1)), (int)((long long)nE * c / (NC - 1)));
+#endif
+    };
+
+    // ---- prologue: first window row staged, its e tile and its first weight chunk built (not overlapped: 1 / win of the work)
+    stage_row(i_lo);
+    __syncthreads();
+    build_e(i_lo, 0, nE);
+    build_weights(i_lo, 0, chunk_end(0), 0);
+
+    int cb = 0;
+    for (int i = i_lo; i < i_hi; ++i) {
+        const unsigned char *const eT = eT0 + (i & 1) * g.e_bytes;
+        int tidm = threadIdx.x;
+        asm volatile("" : "+v"(tidm));
+        bool run;      // does this wave hold any candidate the reference evaluates?  (wave-uniform, see asw_aggregate_kernel)
+        {
+            const int xg = tidm / g.DG, dg = tidm - xg * g.DG;
+            const bool tile_live = tidm < g.XG * g.DG && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
+                                   x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
+            run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
+        }
+        AswRow ew[RX];
+
+        for (int c = 0; c < NC; ++c) {
+            __syncthreads();       // buffers of chunk (i, c) complete; every wave is done with chunk (i, c) - 1
+            const int jc = c * JC, jend = chunk_end(c);
+            const int rb = cb * g.JCmax;
+            // waves 0-3 (one per SIMD) build first, their two SIMD-mates aggregate first and build afterwards
+            if (phase == 0) build_next(i, c, cb);
+#ifndef SSAMD_ABLATE_AGG
+            if (run) {
+                // thread coordinates, e-row pointer and swizzle state are derived per chunk from an opaque thread id:
+                // nothing but the e window and the accumulators stays live across a build
+                int tida = threadIdx.x;
+                asm volatile("" : "+v"(tida));
+                const int xg = tida / g.DG, dg = tida - xg * g.DG;
+                // the next e row to load is ul0 + RX - 1 + jc (ul0 + 0 before the priming of the window row)
+                const unsigned char *erow = eT + (RX * xg + (jc == 0 ? 0 : RX - 1 + jc)) * Se + 4 * dg;
+                if (jc == 0) {
+#pragma unroll
+                    for (int n = 0; n < RX - 1; ++n) {
+                        asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow));
+                        erow += Se;
+                    }
+                }
+                const float *wlp = wL + rb * g.SL + RX * xg;
+                const float *wrp = wR + rb * SR + (RX * xg - ASW_RD * dg + Dc - ASW_RD);
+                for (int j0 = jc; j0 < jend; j0 += RX) {
+#define SSAMD_PSTEP(JJ)                                                                             \
+    if (j0 + (JJ) < jend) {                                                                         \
+        asw_row_unpack(ew[((JJ) + RX - 1) % RX], *reinterpret_cast<const uint32_t *>(erow));        \
+        erow += Se;                                                                                 \
+        float wl[RX], wr[NWR];                                                                      \
+        {                                                                                           \
+            const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                              \
+            const float4 v1 = *reinterpret_cast<const float4 *>(wlp + 4);                          \
+            wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                                 \
+            wl[4] = v1.x; wl[5] = v1.y; wl[6] = v1.z; wl[7] = v1.w;                                 \
+            const float4 r0 = *reinterpret_cast<const float4 *>(wrp);                              \
+            const float4 r1 = *reinterpret_cast<const float4 *>(wrp + 4);                          \
+            const float4 r2 = *reinterpret_cast<const float4 *>(wrp + 8);                          \
+            asm volatile("" ::"v"(r2.w));      /* unused 12th weight: keeps the read a ds_read_b128 */ \
+            wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                                 \
+            wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                                 \
+            wr[8] = r2.x; wr[9] = r2.y; wr[10] = r2.z; wr[11] = r2.w;                               \
+        }                                                                                           \
+        wlp += g.SL; wrp += SR;                                                                     \
+        asw_taps<RX, (JJ)>(accN, accS, wl, wr, ew);                                                 \
+    }
+                    SSAMD_PSTEP(0) SSAMD_PSTEP(1) SSAMD_PSTEP(2) SSAMD_PSTEP(3)
+                    SSAMD_PSTEP(4) SSAMD_PSTEP(5) SSAMD_PSTEP(6) SSAMD_PSTEP(7)
+#undef SSAMD_PSTEP
+                }
+            }
+#endif
+            if (phase != 0) build_next(i, c, cb);
+            cb ^= 1;
+        }
+    }
+
+    // ---- weighted average (_passive.cpp:88) and the two WTA reductions (as asw_aggregate_kernel)
+    int tidf = threadIdx.x;
+    asm volatile("" : "+v"(tidf));
+    if (tidf < g.XG * g.DG) {
+        const int xg = tidf / g.DG, dg = tidf - xg * g.DG;
+        u64 diag[RX + ASW_RD - 1];
+#pragma unroll
+        for (int k = 0; k < RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;
+#pragma unroll
+        for (int xi = 0; xi < RX; ++xi) {
+            const int x = x0 + RX * xg + xi;
+            u64 bl = KEY_NONE;
+#pragma unroll
+            for (int di = 0; di < ASW_RD; ++di) {
+                const int d = dlo + ASW_RD * dg + di;
+                const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
+                if (valid) {
+                    float c;
+                    const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
+                    bl = min(bl, hi | (u64)(uint32_t)d);
+                    diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
+                    if (WITH_COSTS)
+                        A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                }
+            }
+            if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);
+        }
+        if (A.keyR) {
+            const int base = RX * xg - ASW_RD * dg + Dc - ASW_RD;
+#pragma unroll
+            for (int k = 0; k < RX + ASW_RD - 1; ++k)
+                if (diag[k] != KEY_NONE) atomicMin(&bestR[base + k], diag[k]);
+        }
+    }
+    __syncthreads();
+    const size_t orow = (size_t)(y - A.row0) * W;
+    if (A.disp) {
+        for (int k = tid; k < Tx; k += nthr) {
+            const int x = x0 + k;
+            if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
+        }
+        return;
+    }
+    for (int k = tid; k < Tx; k += nthr) {
+        const int x = x0 + k;
+        if (x < W && bestL[k] != KEY_NONE) atomicMin(&A.keyL[orow + x], bestL[k]);
+    }
+    if (A.keyR) {
+        for (int k = tid; k < nRc; k += nthr) {
+            const int xr = xrc_lo + k;
+            if ((unsigned)xr < (unsigned)W && bestR[k] != KEY_NONE) atomicMin(&A.keyR[orow + xr], bestR[k]);
+        }
+    }
+}
+
+}  // namespace ssamd

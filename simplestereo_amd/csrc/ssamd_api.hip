@@ -20,6 +20,7 @@
 
 #include "../../include/ssamd.h"
 #include "asw_kernels.hip.h"
+#include "asw_pipe_kernel.hip.h"
 #include "asw_alt_kernels.hip.h"
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
@@ -238,11 +239,24 @@ int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ ASW geometry
-bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int Rx, bool e2, bool odd_pitch = false)
+bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int Rx, bool e2, bool odd_pitch = false,
+                  bool pipe = false)
 {
     g.Rx = Rx;
     g.JC = JC >= win ? win : JC;                 // tap columns staged per chunk; win = the whole row at once
-    const int wrows = g.JC < win ? 2 * g.JC : win;   // chunk buffers alternate
+    g.pipe = 0; g.NC = 1; g.JCmax = g.JC; g.dephase = 0;
+    if (pipe) {
+        // phase-shifted kernel (asw_pipe_kernel.hip.h): chunks start at multiples of JC (8 or 16), a tail shorter than
+        // the 8-column register tile is merged into the last chunk; needs >= 2 chunks, two e tiles, the 8-column tile
+        if (Rx != 8 || (JC != 8 && JC != 16) || win / JC < 2 || !e2) return false;
+        g.pipe = 1;
+        // waves 0-3 build before they aggregate (see the kernel): pays with three waves per SIMD (12-wave groups:
+        // 1080p/193 41.8 -> 41.0 ms), costs with two (640x480/65, 8 waves: 3.11 -> 3.26 ms)
+        g.dephase = getenv("SSAMD_ASW_DEPHASE") ? atoi(getenv("SSAMD_ASW_DEPHASE")) : (round_up(XG * DG, 64) / 64 >= 12 ? 1 : 0);
+        g.NC = win / JC;
+        g.JCmax = win - (g.NC - 1) * JC;
+    }
+    const int wrows = g.pipe ? 2 * g.JCmax : (g.JC < win ? 2 * g.JC : win);   // chunk buffers alternate
     const int wcols = g.JC;                      // tap columns a weight-build pass covers
 
     const int p = win / 2;
@@ -267,6 +281,19 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
         g.Se = 4 * (DG | 1);
         g.emask = 0;
     }
+    if (g.pipe) {
+        // plain rows, lanes along the disparity groups (asw_pipe_kernel.hip.h): a thread reads floats
+        // [8 xg, 8 xg + 8) of a wL row and [8 xg - 4 dg + Dc - 4, + 12) of a wR row (the last one is index nRc, unused)
+        g.hL = g.hR = 0;
+        g.SL = round_up(g.Tx, 4);
+        g.SR = round_up(g.nRc + 1, 4);
+        // e row pitch in dwords: == 2 (mod 4), so that where a 32-lane group crosses from one column group (rows RX
+        // apart) to the next the two runs of dwords fall on different banks
+        int P = DG;
+        while ((P & 3) != 2) ++P;
+        g.Se = 4 * P;
+        g.emask = 0;
+    }
     // weight build balance: (centres x segments) tasks over the workgroup's threads
     {
         const int ncen = g.Tx + g.nRc;
@@ -283,6 +310,7 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
     g.off_wR = take((size_t)wrows * g.SR * 4);
     g.e_bytes = (int)(((size_t)g.nL * g.Se + 15) & ~(size_t)15);
     g.e2 = (e2 && g.JC < win && (win + g.JC - 1) / g.JC >= 2) ? 1 : 0;
+    if (g.pipe && !g.e2) return false;
     g.off_e = take((size_t)g.e_bytes * (g.e2 ? 2 : 1));
     g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
     g.off_labR = take((size_t)g.nR * 16 * 2);
@@ -341,6 +369,25 @@ void asw_pick_e_scheme(AswGeom &g, int win)
     }
 }
 
+// Phase-shifted kernel for a chosen tile (asw_pipe_kernel.hip.h): same XG x DG thread grid and register tile, tap
+// columns in chunks of 8 (or 16) with the tail merged, two e tiles.  Taken whenever it fits (8-column tile, window of
+// at least two chunks, LDS); the sums and their order are those of asw_aggregate_kernel, so maps do not change.
+// SSAMD_ASW_PIPE=0 disables it, =8 / =16 force the chunk length (experiments and tests).
+void asw_try_pipe(AswGeom &g, int win)
+{
+    int want = -1;
+    if (const char *env = getenv("SSAMD_ASW_PIPE")) want = atoi(env);
+    if (want == 0 || g.Rx != 8) return;
+    for (int JC : {16, 8}) {
+        if (want > 0 && JC != want) continue;
+        AswGeom alt;
+        if (!asw_layout_e(alt, win, g.XG, g.DG, 160 * 1024, JC, 8, true, false, true)) continue;
+        alt.nchunks = g.nchunks;
+        g = alt;
+        return;
+    }
+}
+
 // Pick the workgroup tile (XG column groups x DG disparity groups, nchunks disparity chunks)
 // with an occupancy-aware cost model calibrated on MI355X (profiles/r01_*):
 //   - the kernel needs 168 VGPRs -> 3 waves per SIMD; a workgroup of w waves puts ceil(w/4)
@@ -391,6 +438,7 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe, Rx)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
             asw_pick_e_scheme(best, win);
+            asw_try_pipe(best, win);
             return SSAMD_OK;
         }
     }
@@ -460,14 +508,19 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             best = g;
         }
     }
-    if (found) asw_pick_e_scheme(best, win);
+    if (found) { asw_pick_e_scheme(best, win); asw_try_pipe(best, win); }
     if (shortlist && found) {
         std::vector<std::pair<double, AswGeom>> v;
         for (auto &kv : classes) v.push_back(kv.second);
         std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         shortlist->clear();
-        for (size_t i = 0; i < v.size() && i < 10 && v[i].first > 0.6 * best_score; ++i) {
+        // every class enters in its phase-shifted form where that exists AND in the plain form: which of the two is
+        // faster depends on the tile (waves per SIMD, centres per thread), and the trials measure it
+        for (size_t i = 0; i < v.size() && i < 8 && v[i].first > 0.6 * best_score && shortlist->size() < 12; ++i) {
             asw_pick_e_scheme(v[i].second, win);
+            AswGeom piped = v[i].second;
+            asw_try_pipe(piped, win);
+            if (piped.pipe) shortlist->push_back(piped);
             shortlist->push_back(v[i].second);
         }
     }
@@ -611,6 +664,13 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.disp = is_direct(g) ? d_disp : nullptr;
             const dim3 grid((W + g.Tx - 1) / g.Tx, grows, g.nchunks), block(g.threads);
             const bool chunked = g.JC < win;
+            if (g.pipe) {
+                auto pk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
+                if (int grc = grant_dyn_lds(c, (const void *)pk, g.lds_bytes)) return grc;
+                hipLaunchKernelGGL(pk, grid, block, g.lds_bytes, s, a);
+                HIP_TRY(hipGetLastError());
+                return SSAMD_OK;
+            }
             auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
                                 : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
             if (g.Rx == 4)

@@ -166,6 +166,40 @@ def test_asw_forced_geometries_and_chunked_staging_agree(geom, ss, golden_inputs
     assert np.array_equal(got_one_e, want) and np.array_equal(got_xor, want)
 
 
+@pytest.mark.parametrize("geom,win", [("6,5,8", 21), ("10,9,16", 35), ("3,9,8", 17), ("12,3,8", 35), ("15,13,16", 35), ("9,17,8", 33),
+                                      ("4,30,16", 41), ("16,12,8", 16), ("2,3,8", 39)])
+def test_asw_phase_shifted_kernel_equals_the_plain_one(geom, win, ss, golden_inputs):
+    """asw_aggregate_pipe_kernel (lanes along the disparity groups, plain LDS rows, waves 0-3 building before they
+    aggregate, tail-merged tap-column chunks of 8 or 16) accumulates the same taps in the same order as
+    asw_aggregate_kernel: for forced tiles, windows whose last chunk is 8..15 columns long, both chunk lengths and
+    the wave order switched on and off, the maps are those of the plain kernel bit for bit (consistent mode: both
+    argmins and the raw cost dump as well)"""
+    a, b = golden_inputs("synth_96x128")
+    XG, DG, JC = (int(v) for v in geom.split(","))
+    maxd = DG * 4 - 2
+    m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, minDisparity=1, consistent=True, gammaC=7.0)
+    from simplestereo_amd import _native
+    H, W = a.shape[:2]
+
+    def costs():
+        c = np.empty((H, W, maxd), np.float32)
+        _native.check(_native.lib().ssamd_asw_costs(a.ctypes.data, b.ctypes.data, H, W, win, maxd, 1, 7.0, 17.5, c.ctypes.data, -1))
+        return c
+    os.environ["SSAMD_ASW_GEOM"] = "%d,%d,0,8" % (XG, DG)          # the tile, whole window rows, plain kernel
+    os.environ["SSAMD_ASW_PIPE"] = "0"
+    try:
+        want, want_c = m.compute(a, b), costs()
+        for dephase in ("0", "1"):
+            os.environ["SSAMD_ASW_PIPE"] = str(JC)
+            os.environ["SSAMD_ASW_DEPHASE"] = dephase
+            got, got_c = m.compute(a, b), costs()
+            assert np.array_equal(got, want), (geom, win, dephase)
+            assert np.array_equal(got_c, want_c, equal_nan=True), (geom, win, dephase)
+    finally:
+        for k in ("SSAMD_ASW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE"):
+            os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("H,W,maxd,shift", [(1080, 1920, 192, 150), (2160, 4096, 256, 233)])
 def test_asw_full_size_configs_3_and_5_known_shift_and_strip_invariance(H, W, maxd, shift, ss):
     """BASELINE configs 3 and 5 at full size, through size-independent properties: (1) a right image that is the
