@@ -66,6 +66,9 @@ struct AswArgs {
     u64 *keyR;                   // [rows][W] right-referenced WTA keys (cost, xl) or nullptr
     int16_t *disp;               // non-null: ONE disparity chunk and no right pass -- every pixel is decided by exactly one
                                  //   workgroup, which writes the disparity itself (no keys, no atomics, no decode kernel)
+    const unsigned char *evol;   // phase-shifted kernel: truncated-absolute-difference volume of asw_tad_volume_kernel (or nullptr:
+                                 //   e tiles are built in the kernel), [disparity chunk][image row - erow0][evolW columns][g.Se bytes]
+    int erow0, erows, evolW;
     float *costs;                // optional [rows][W][nD] raw cost dump
     int H, W, win, pad, minD, maxD, row0, rows;
     int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)

@@ -41,6 +41,39 @@
 
 namespace ssamd {
 
+// K0e: the truncated absolute differences e[r][u][d] = min(40, |dB|+|dG|+|dR|) of L[r][u] and R[r][u-d]
+// (_passive.cpp:77-79) for every image row the launch touches, as bytes in exactly the layout of the kernel's e
+// tiles: [disparity chunk z][row][column u + pad][Se bytes = one dword per 4 disparities, padded].  e depends on
+// (r, u, d) only, so each value is needed by the up to winSize window rows of winSize output rows: built once here
+// (H*W*nD bytes: 0.4 GB at 1080p / 193, a 0.1 ms HBM-bound kernel) instead of winSize times inside the aggregation
+// kernel, whose workgroups then fetch their tiles with LDS-DMA (global_load_lds_dwordx4: no VALU work, no
+// registers).  Columns or disparities outside the image get 0; their taps carry weight 0.
+__global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__restrict__ recL, const PixRec *__restrict__ recR,
+                                                             unsigned char *__restrict__ evol, int W, int pad, int minD, int Dc,
+                                                             int Se, int erow0, int erows, int evolW)
+{
+    const int r = erow0 + blockIdx.y, z = blockIdx.z;
+    const int P = Se >> 2;                                       // dwords per column
+    const long long n = (long long)evolW * P;
+    uint32_t *const out = reinterpret_cast<uint32_t *>(evol + ((size_t)z * erows + blockIdx.y) * (size_t)evolW * Se);
+    const PixRec *const rowL = recL + (size_t)r * W, *const rowR = recR + (size_t)r * W;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        const int uc = (int)(k / P), slot = (int)(k - (long long)uc * P);
+        const int u = uc - pad, d0 = minD + z * Dc + 4 * slot;
+        uint32_t v = 0;
+        if ((unsigned)u < (unsigned)W && 4 * slot < Dc) {
+            const uint32_t lp = rowL[u].bgrx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xr = u - d0 - q;
+                const uint32_t rp = (unsigned)xr < (unsigned)W ? rowR[xr].bgrx : 0u;
+                v |= min(__builtin_amdgcn_sad_u8(lp, rp, 0u), 40u) << (8 * q);
+            }
+        }
+        out[k] = v;
+    }
+}
+
 template <bool WITH_COSTS>
 __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(const AswArgs A)
 {
@@ -149,6 +182,20 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
             if (ul >= nL) { ul -= nL; ++sp; }
         }
     };
+    // the e tile of window row i fetched from the pre-computed volume (A.evol) by LDS-DMA: the tile is ONE contiguous
+    // block of nL columns x Se bytes there; every wave moves 1 KiB pieces (64 lanes x 16 B) straight into LDS
+    auto load_e = [&](int i) {
+        int tidd = threadIdx.x;
+        asm volatile("" : "+v"(tidd));
+        const int r = y - p + i;
+        const unsigned char *const src = A.evol + (((size_t)blockIdx.z * A.erows + (r - A.erow0)) * (size_t)A.evolW + x0) * Se;
+        unsigned char *const dst = eT0 + (i & 1) * g.e_bytes;
+        const int bytes = nL * Se, lane16 = (tidd & 63) * 16;
+        for (int k = __builtin_amdgcn_readfirstlane(tidd >> 6) * 1024; k < bytes; k += (nthr >> 6) * 1024)
+            if (k + lane16 < bytes)
+                __builtin_amdgcn_global_load_lds((const void *)(src + k + lane16),
+                                                 (__attribute__((address_space(3))) void *)(dst + k), 16, 0, 0);
+    };
     // support weights of window row i, tap columns [jb, je), into weight buffer rows rb.. (_passive.cpp:47-50, 71-74;
     // exp(-dist/gammaC) = exp2(dist*kC)).  One thread per window centre, all columns of the chunk: batches of ASW_WB
     // independent chains walking running pointers; taps or centres outside the image get weight 0 through a mask.
@@ -249,19 +296,23 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
 #ifndef SSAMD_ABLATE_STAGE
         if (c == 0 && more_rows) stage_row(i + 1);
 #endif
+        // issued after the staged pixels are in LDS (their global loads are waited for with vmcnt(0), which would
+        // also wait for these); lands under the chunk's taps, complete at the next barrier
+        if (c == 0 && more_rows && A.evol) load_e(i + 1);
 #ifndef SSAMD_ABLATE_WEIGHTS
         if (c + 1 < NC) build_weights(i, (c + 1) * JC, chunk_end(c + 1), (cb ^ 1) * g.JCmax);
         else if (more_rows) build_weights(i + 1, 0, chunk_end(0), (cb ^ 1) * g.JCmax);
 #endif
 #ifndef SSAMD_ABLATE_E
-        if (c >= 1 && more_rows) build_e(i + 1, (int)((long long)nE * (c - 1) / (NC - 1)), (int)((long long)nE * c / (NC - 1)));
+        if (c >= 1 && more_rows && !A.evol) build_e(i + 1, (int)((long long)nE * (c - 1) / (NC - 1)), (int)((long long)nE * c / (NC - 1)));
 #endif
     };
 
     // ---- prologue: first window row staged, its e tile and its first weight chunk built (not overlapped: 1 / win of the work)
     stage_row(i_lo);
+    if (A.evol) load_e(i_lo);
     __syncthreads();
-    build_e(i_lo, 0, nE);
+    if (!A.evol) build_e(i_lo, 0, nE);
     build_weights(i_lo, 0, chunk_end(0), 0);
 
     int cb = 0;

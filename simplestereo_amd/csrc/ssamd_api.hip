@@ -129,7 +129,7 @@ struct Ctx {
     int dev = -1;
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
-    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq;
+    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol;
     TableCache proxTabs{8}, gswTabs{4};
     std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
@@ -287,11 +287,9 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
         g.hL = g.hR = 0;
         g.SL = round_up(g.Tx, 4);
         g.SR = round_up(g.nRc + 1, 4);
-        // e row pitch in dwords: == 2 (mod 4), so that where a 32-lane group crosses from one column group (rows RX
-        // apart) to the next the two runs of dwords fall on different banks
-        int P = DG;
-        while ((P & 3) != 2) ++P;
-        g.Se = 4 * P;
+        // e rows: one dword per disparity group, pitch a multiple of 16 bytes so that a tile is an aligned contiguous
+        // block of the pre-computed volume (LDS-DMA moves 16 bytes per lane)
+        g.Se = 16 * ((DG + 3) / 4);
         g.emask = 0;
     }
     // weight build balance: (centres x segments) tasks over the workgroup's threads
@@ -380,6 +378,9 @@ void asw_try_pipe(AswGeom &g, int win)
     if (want == 0 || g.Rx != 8) return;
     for (int JC : {16, 8}) {
         if (want > 0 && JC != want) continue;
+        // chunks of 8 double the barriers per window row: measured to pay only with three waves per SIMD
+        // (4096x2160/257: 265 -> 245 ms, 1080p/129/win 21: 12.7 -> 11.3 ms; 8-wave tiles lose 5-15 %)
+        if (want < 0 && JC == 8 && round_up(g.XG * g.DG, 64) / 64 < 12) continue;
         AswGeom alt;
         if (!asw_layout_e(alt, win, g.XG, g.DG, 160 * 1024, JC, 8, true, false, true)) continue;
         alt.nchunks = g.nchunks;
@@ -658,6 +659,28 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
         a.ystep = alternate ? 2 : 1;
+        a.evol = nullptr; a.erow0 = r0; a.erows = r1 - r0; a.evolW = 0;
+        // pre-computed truncated-absolute-difference volume for the phase-shifted kernel (asw_tad_volume_kernel);
+        // SSAMD_ASW_EVOL=0 keeps the in-kernel e tiles (experiments / tests)
+        auto prepare_evol = [&](const AswGeom &g) -> int {
+            a.evol = nullptr;
+            if (!g.pipe || (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0)) return SSAMD_OK;
+            const int xt = (W + g.Tx - 1) / g.Tx;
+            const int evolW = xt * g.Tx + 2 * p;
+            const size_t bytes = (size_t)g.nchunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)g.Se;
+            if (bytes > ((size_t)24 << 30)) return SSAMD_OK;          // very large frames: build the tiles in the kernel
+            int erc = c.evol.reserve(bytes + 4096);                     // + one DMA piece of slack behind the last tile
+            if (erc) return erc;
+            a.evol = (const unsigned char *)c.evol.ptr;
+            a.evolW = evolW;
+            Timed t(c, s, SSAMD_K_LAB);
+            const long long per_row = (long long)evolW * (g.Se / 4);
+            const dim3 egrid((unsigned)std::min<long long>((per_row + 255) / 256, 64), (unsigned)(r1 - r0), (unsigned)g.nchunks);
+            hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), 0, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
+                               (unsigned char *)c.evol.ptr, W, p, minD, g.Dc, g.Se, r0, r1 - r0, evolW);
+            HIP_TRY(hipGetLastError());
+            return SSAMD_OK;
+        };
         auto launch = [&](const AswGeom &g) -> int {
             a.g = g;
             a.keyL = is_direct(g) ? nullptr : (u64 *)c.keyL.ptr;
@@ -689,11 +712,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             // first launches after an idle period, so timing the candidates one after the other would favour the
             // late ones
             std::vector<float> cand_ms(trial.size(), 3.0e38f);
-            for (const AswGeom &g : trial) (void)launch(g);                  // code load, clocks
+            for (const AswGeom &g : trial) { (void)prepare_evol(g); (void)launch(g); }    // code load, clocks, scratch
             for (int round = 0; round < 4; ++round)
                 for (size_t ci = 0; ci < trial.size(); ++ci) {
                     float ms = 3.0e38f;
-                    if (hipEventRecord(e0, s) == hipSuccess && launch(trial[ci]) == SSAMD_OK &&
+                    if (hipEventRecord(e0, s) == hipSuccess && prepare_evol(trial[ci]) == SSAMD_OK && launch(trial[ci]) == SSAMD_OK &&
                         hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
                         (void)hipEventElapsedTime(&ms, e0, e1);
                     if (round > 0) cand_ms[ci] = std::min(cand_ms[ci], ms);  // round 0 is warm-up
@@ -714,6 +737,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         }
         {
             const AswGeom final_geom = a.g;
+            if ((rc = prepare_evol(final_geom))) return rc;
             Timed t(c, s, SSAMD_K_ASW_AGG);
             if ((rc = launch(final_geom))) return rc;
         }
