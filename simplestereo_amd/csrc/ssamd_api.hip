@@ -248,13 +248,16 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
     if (pipe) {
         // phase-shifted kernel (asw_pipe_kernel.hip.h): chunks start at multiples of JC (8 or 16), a tail shorter than
         // the 8-column register tile is merged into the last chunk; needs >= 2 chunks, two e tiles, the 8-column tile
-        if (Rx != 8 || (JC != 8 && JC != 16) || win / JC < 2 || !e2) return false;
+        // chunk starts are multiples of JC (itself a multiple of the register tile's columns); the chunk count is
+        // win / JC rounded, the last chunk takes what is left (win 35: JC 16 -> 16, 19; JC 8 -> 8, 8, 8, 11; JC 12 -> 12, 12, 11)
+        if (Rx != 8 || JC % Rx || !e2) return false;
+        g.NC = (win + JC / 2) / JC;
+        if (g.NC < 2 || (g.NC - 1) * JC >= win) return false;
         g.pipe = 1;
-        // waves 0-3 build before they aggregate (see the kernel): pays with three waves per SIMD (12-wave groups:
-        // 1080p/193 41.8 -> 41.0 ms), costs with two (640x480/65, 8 waves: 3.11 -> 3.26 ms)
+        // waves 0-3 build before they aggregate (see the kernel): pays with three or four waves per SIMD (12-wave
+        // groups: 1080p/193 41.8 -> 41.0 ms), costs with two (640x480/65, 8 waves: 3.11 -> 3.26 ms)
         g.dephase = getenv("SSAMD_ASW_DEPHASE") ? atoi(getenv("SSAMD_ASW_DEPHASE")) : (round_up(XG * DG, 64) / 64 >= 12 ? 1 : 0);
-        g.NC = win / JC;
-        g.JCmax = win - (g.NC - 1) * JC;
+        g.JCmax = std::max(JC, win - (g.NC - 1) * JC);
     }
     const int wrows = g.pipe ? 2 * g.JCmax : (g.JC < win ? 2 * g.JC : win);   // chunk buffers alternate
     const int wcols = g.JC;                      // tap columns a weight-build pass covers
