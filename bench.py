@@ -28,9 +28,9 @@ Rank 0 prints ONE JSON line.  metric = disparity MPixels/s = H*W*nD / t / 1e6
                 default D 0..16, and GSW config 4), each with its own kernel time and VALU fraction.
   cpu_baseline  the reference's own C++ extension (oracle/_ref, kind "reference") or
                 the plain-C port (oracle/, kind "port", literal mode) timed on this
-                box's host cores on a bounded strip of the same frame with >= 2 rows per
-                host thread (the reference hands out one row per job, _passive.cpp:372-374),
-                so that every thread is busy; plus "hoisted": the plain-C port with the same
+                box's host cores on a bounded crop of the same frame with one row per host
+                thread (the reference hands out one row per job, _passive.cpp:372-374), so that
+                every thread is busy, 512 columns wide so that it stays within ~30 s; plus "hoisted": the plain-C port with the same
                 algebraic shortcut as the GPU (right weights evaluated once per pixel, not once
                 per candidate), kind "port-hoisted", timed the same way.
   bad1_vs_cpu_ref  the second half of BASELINE's metric: % of pixels of that strip whose GPU
@@ -89,13 +89,18 @@ def count_taps(H, W, win, maxD, minD, row0=0, rows=None):
     return int(vrows.sum()) * int(cols.sum())
 
 
-def cpu_baseline(cfg, seed, rows_per_thread=2, timeout_s=900):
-    """Time the reference (and the hoisted plain-C port) on a bounded strip of the same frame, on the host cores.
+def cpu_baseline(cfg, seed, rows_per_thread=1, timeout_s=900, crop_cols=512):
+    """Time the reference (and the hoisted plain-C port) on a bounded crop of the same frame, on the host cores.
 
     The reference hands out ONE image row per job to hardware_concurrency() threads (_passive.cpp:352-355, 372-396),
-    so a strip keeps every host thread busy only if it has at least as many rows as there are threads: the strip is
-    the centre `rows_per_thread x threads` rows of the frame (whole frame if that is more than it has)."""
+    so a sample keeps every host thread busy only if it has at least as many rows as there are threads: the sample is
+    the centre `rows_per_thread x threads` rows of the frame.  To keep that within the 10-30 s of CPU work the bench
+    contract allows (the reference does ~1e9 window taps per second on 256 threads; a full-width 1080p strip of 512
+    rows took 190-215 s, profiles/r02_b_bench_full_cpu_strip.json), the rows are cropped to the centre `crop_cols`
+    columns: equal-cost row jobs, one or more per thread, scaled to the full frame by the exact tap count."""
     H, W, maxD, minD, win = cfg
+    cols = min(W, crop_cols)
+    c0 = (W - cols) // 2
     code = r"""
 import sys, time, json, os
 sys.path.insert(0, %r)
@@ -106,7 +111,8 @@ H, W, maxD, minD, win, rows, seed = %d, %d, %d, %d, %d, int(sys.argv[1]), %d
 mode = sys.argv[3]
 L, R, _ = make_pair(H, W, maxD, seed)
 r0 = (H - rows) // 2
-a, b = np.ascontiguousarray(L[r0:r0 + rows]), np.ascontiguousarray(R[r0:r0 + rows])
+c0, cols = int(sys.argv[4]), int(sys.argv[5])
+a, b = np.ascontiguousarray(L[r0:r0 + rows, c0:c0 + cols]), np.ascontiguousarray(R[r0:r0 + rows, c0:c0 + cols])
 ref = oracle.ref_module() if mode == "reference" else None
 oracle.asw(a[:2, :64], b[:2, :64], 5, 4, 0, %r, %r)       # load the library outside the timed region
 t = time.time()
@@ -126,8 +132,8 @@ print(json.dumps({"t": dt, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}
     dump_h = os.path.join(tempfile.gettempdir(), "ssamd_cpu_hoist_%d.npy" % os.getpid())
 
     def run(rows, mode, path):
-        out = subprocess.run([sys.executable, "-c", code, str(rows), path, mode], capture_output=True, text=True,
-                             timeout=timeout_s)      # the reference's queue has an empty()/pop() race: bounded wait
+        out = subprocess.run([sys.executable, "-c", code, str(rows), path, mode, str(c0), str(cols)], capture_output=True,
+                             text=True, timeout=timeout_s)      # the reference's queue has an empty()/pop() race: bounded wait
         res = json.loads(out.stdout.strip().splitlines()[-1])
         res["rows"] = rows
         return res
@@ -135,17 +141,19 @@ print(json.dumps({"t": dt, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}
     cores = os.cpu_count() or 1
     rows = min(H, max(rows_per_thread * cores, 8))
     full = count_taps(H, W, win, maxD, minD)
-    taps = count_taps(rows, W, win, maxD, minD)          # the strip is matched as a stand-alone sub-image
+    taps = count_taps(rows, cols, win, maxD, minD)       # the crop is matched as a stand-alone sub-image
     nD = maxD - minD + 1
 
     def entry(res):
         t_full = res["t"] * full / taps                  # per-tap cost is uniform
         return {"value": H * W * nD / t_full / 1e6, "unit": "MPixels*disp/s", "cores": res["cores"], "kind": res["kind"],
-                "strip_row0": res["r0"], "strip_rows": rows, "threads_busy": min(rows, res["cores"]),
+                "strip_row0": res["r0"], "strip_rows": rows, "strip_col0": c0, "strip_cols": cols,
+                "threads_busy": min(rows, res["cores"]),
                 "rows_per_thread": rows / float(res["cores"]), "wall_s": res["t"],
-                "sample": "%dx%d centre strip (%d rows = %.1f row jobs per host thread) of the same frame, %.3g of the "
-                          "frame's %.4g window taps, %.1f s wall on %d host threads; scaled to the full frame by tap count" %
-                          (W, rows, rows, rows / float(res["cores"]), taps / full, float(full), res["t"], res["cores"])}
+                "sample": "%dx%d centre crop (%d rows = %.1f row jobs per host thread, %d of %d columns) of the same frame, "
+                          "%.3g of the frame's %.4g window taps, %.1f s wall on %d host threads; scaled to the full frame by "
+                          "exact tap count" %
+                          (cols, rows, rows, rows / float(res["cores"]), cols, W, taps / full, float(full), res["t"], res["cores"])}
     try:
         cb = entry(run(rows, "reference", dump))
         cb["map_file"] = dump
@@ -281,8 +289,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations (extra JSON key `others`)")
-    ap.add_argument("--cpu-rows-per-thread", type=int, default=2,
-                    help="cpu_baseline strip height in rows per host thread (the reference schedules one row per job)")
+    ap.add_argument("--cpu-rows-per-thread", type=int, default=1,
+                    help="cpu_baseline sample height in rows per host thread (the reference schedules one row per job)")
+    ap.add_argument("--cpu-crop-cols", type=int, default=512,
+                    help="cpu_baseline sample width (centre columns); 0 = full width (minutes of CPU time at 1080p)")
     ap.add_argument("--with-alternate", action="store_true",
                     help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
     args = ap.parse_args()
@@ -419,17 +429,19 @@ def main():
         if world == 1 and not args.no_others:
             line["others"] = others(dev, args.seed)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread)
+            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1])
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
             # the CPU baseline computed (matched as a stand-alone sub-image by both)
             try:
                 ref_map = np.load(cb["map_file"])
                 os.remove(cb["map_file"])
-                r0s, rws = cb["strip_row0"], cb["strip_rows"]
-                gpu_map = matcher.compute(np.ascontiguousarray(L[r0s:r0s + rws]), np.ascontiguousarray(R[r0s:r0s + rws]))
+                r0s, rws, c0s, cls = cb["strip_row0"], cb["strip_rows"], cb["strip_col0"], cb["strip_cols"]
+                gpu_map = matcher.compute(np.ascontiguousarray(L[r0s:r0s + rws, c0s:c0s + cls]),
+                                          np.ascontiguousarray(R[r0s:r0s + rws, c0s:c0s + cls]))
                 diff = np.abs(gpu_map.astype(np.int32) - ref_map.astype(np.int32))
                 line["bad1_vs_cpu_ref"] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
-                                           "pixels": int(diff.size), "what": "GPU vs CPU %s map of the cpu_baseline strip" % cb["kind"]}
+                                           "pixels": int(diff.size), "what": "GPU vs CPU %s map of the cpu_baseline crop (the 1920- and "
+                                           "4096-wide launch geometries are pinned by tests/test_gpu_wide_golden.py)" % cb["kind"]}
             except Exception as e:      # noqa: BLE001
                 line["bad1_vs_cpu_ref"] = {"percent": None, "what": repr(e)[:160]}
             cb.pop("map_file", None)

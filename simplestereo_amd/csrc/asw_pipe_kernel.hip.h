@@ -48,26 +48,42 @@ namespace ssamd {
 // (H*W*nD bytes: 0.4 GB at 1080p / 193, a 0.1 ms HBM-bound kernel) instead of winSize times inside the aggregation
 // kernel, whose workgroups then fetch their tiles with LDS-DMA (global_load_lds_dwordx4: no VALU work, no
 // registers).  Columns or disparities outside the image get 0; their taps carry weight 0.
+// Workgroup = one image row x 64 columns x one disparity chunk.  The pixels are staged in LDS (coalesced record
+// reads), every thread then produces whole dwords (4 disparities) of one column, and the 64 x Se byte block -- a
+// contiguous piece of the volume -- is written with consecutive lanes on consecutive dwords.
+static constexpr int TADV_COLS = 64;
 __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__restrict__ recL, const PixRec *__restrict__ recR,
                                                              unsigned char *__restrict__ evol, int W, int pad, int minD, int Dc,
                                                              int Se, int erow0, int erows, int evolW)
 {
-    const int r = erow0 + blockIdx.y, z = blockIdx.z;
-    const int P = Se >> 2;                                       // dwords per column
-    const long long n = (long long)evolW * P;
-    uint32_t *const out = reinterpret_cast<uint32_t *>(evol + ((size_t)z * erows + blockIdx.y) * (size_t)evolW * Se);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *const sL = reinterpret_cast<uint32_t *>(smem);                 // [TADV_COLS]
+    uint32_t *const sR = sL + TADV_COLS;                                     // [TADV_COLS + Dc]: right columns u0 - dhi .. u0 + 63 - dlo
+    const int r = erow0 + blockIdx.y, z = blockIdx.z, uc0 = blockIdx.x * TADV_COLS;
+    const int P = Se >> 2, dlo = minD + z * Dc, dhi = dlo + Dc - 1;
+    const int u0 = uc0 - pad, xr0 = u0 - dhi;
     const PixRec *const rowL = recL + (size_t)r * W, *const rowR = recR + (size_t)r * W;
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-        const int uc = (int)(k / P), slot = (int)(k - (long long)uc * P);
-        const int u = uc - pad, d0 = minD + z * Dc + 4 * slot;
+    for (int k = threadIdx.x; k < 2 * TADV_COLS + Dc; k += blockDim.x) {
+        const bool isL = k < TADV_COLS;
+        const int col = isL ? u0 + k : xr0 + (k - TADV_COLS);
+        // bit 31 marks a column outside the image (pixel bytes never set it): its e values are 0
+        const uint32_t v = (unsigned)col < (unsigned)W ? (isL ? rowL : rowR)[col].bgrx : 0x80000000u;
+        (isL ? sL : sR)[isL ? k : k - TADV_COLS] = v;
+    }
+    __syncthreads();
+    const int ncols = min(TADV_COLS, evolW - uc0);
+    uint32_t *const out = reinterpret_cast<uint32_t *>(evol + (((size_t)z * erows + blockIdx.y) * (size_t)evolW + uc0) * Se);
+    for (int k = threadIdx.x; k < ncols * P; k += blockDim.x) {
+        const int c = k / P, slot = k - c * P;
+        const uint32_t lp = sL[c];
         uint32_t v = 0;
-        if ((unsigned)u < (unsigned)W && 4 * slot < Dc) {
-            const uint32_t lp = rowL[u].bgrx;
+        if (!(lp >> 31) && 4 * slot < Dc) {
+            // R[u - d] for d = dlo + 4 slot + q  ->  staged index c + (Dc - 1) - 4 slot - q
+            const uint32_t *const rp = sR + c + (Dc - 1) - 4 * slot;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int xr = u - d0 - q;
-                const uint32_t rp = (unsigned)xr < (unsigned)W ? rowR[xr].bgrx : 0u;
-                v |= min(__builtin_amdgcn_sad_u8(lp, rp, 0u), 40u) << (8 * q);
+                const uint32_t rv = 4 * slot + q < Dc ? rp[-q] : 0x80000000u;
+                if (!(rv >> 31)) v |= min(__builtin_amdgcn_sad_u8(lp, rv, 0u), 40u) << (8 * q);
             }
         }
         out[k] = v;

@@ -677,9 +677,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.evol = (const unsigned char *)c.evol.ptr;
             a.evolW = evolW;
             Timed t(c, s, SSAMD_K_LAB);
-            const long long per_row = (long long)evolW * (g.Se / 4);
-            const dim3 egrid((unsigned)std::min<long long>((per_row + 255) / 256, 64), (unsigned)(r1 - r0), (unsigned)g.nchunks);
-            hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), 0, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
+            const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), (unsigned)g.nchunks);
+            const size_t elds = (size_t)(2 * TADV_COLS + g.Dc) * 4;
+            hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), elds, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
                                (unsigned char *)c.evol.ptr, W, p, minD, g.Dc, g.Se, r0, r1 - r0, evolW);
             HIP_TRY(hipGetLastError());
             return SSAMD_OK;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: A/B of ASW kernel variants selected by environment variables (each variant in its own process, because launch
-geometries are cached per shape).  usage: tools/ab_asw.py [--quick] name=ENV1=v,ENV2=v ...   (name "base" = no env)
+geometries are cached per shape).  usage: tools/ab_asw.py [--quick] [--only=case,..] "name=ENV1=v;ENV2=v" ...   (name "base" = no env)
 Prints kernel ms per configuration and checks that every variant's maps equal the first variant's bit for bit."""
 import json
 import os
@@ -53,7 +53,7 @@ def main():
     variants = []
     for a in args or ["base"]:
         name, _, envs = a.partition("=")
-        env = dict(kv.split("=", 1) for kv in envs.split(",") if kv) if envs else {}
+        env = dict(kv.split("=", 1) for kv in envs.split(";") if kv) if envs else {}      # name=ENV1=v;ENV2=v
         variants.append((name, env))
     import numpy as np
     results, ref = {}, None
