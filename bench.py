@@ -380,6 +380,7 @@ def main():
         achieved_gbs = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         achieved_ops = VALU_OPS_PER_TAP * taps_here / (k_ms * 1e-3) if k_ms > 0 else None
         geom = _native.asw_geometry(W, rows_here, win, maxD, minD)
+        geom.update(_native.asw_kernel_form(W, rows_here, win, maxD, minD))
         traffic, traffic_source, issue = replayed_counters(args.config, k_ms) if world == 1 else (None, None, None)
         line = {
             "metric": "disparity MPixels/s (H*W*nDisp per second)",

@@ -82,6 +82,8 @@ def lib():
     L.ssamd_autotune.argtypes = [I]
     L.ssamd_asw_geometry.restype = I
     L.ssamd_asw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
+    L.ssamd_asw_kernel_form.restype = I
+    L.ssamd_asw_kernel_form.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
     L.ssamd_gsw_geometry.restype = I
     L.ssamd_gsw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
     if L.ssamd_abi_version() != 1:
@@ -107,6 +109,12 @@ def asw_geometry(width, rows, winSize, maxDisparity, minDisparity):
     check(lib().ssamd_asw_geometry(width, rows, winSize, maxDisparity, minDisparity, out))
     keys = ("tile_x", "chunk_d", "n_chunks", "threads", "lds_bytes", "grid_x", "grid_y", "grid_z")
     return dict(zip(keys, list(out)))
+
+
+def asw_kernel_form(width, rows, winSize, maxDisparity, minDisparity):
+    out = (ctypes.c_int * 4)()
+    check(lib().ssamd_asw_kernel_form(width, rows, winSize, maxDisparity, minDisparity, out))
+    return dict(zip(("phase_shifted", "tile_columns", "chunk_columns", "build_first_waves"), list(out)))
 
 
 def gsw_geometry(width, rows, winSize, maxDisparity, minDisparity):

@@ -1122,6 +1122,19 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
     return SSAMD_OK;
 }
 
+int ssamd_asw_kernel_form(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
+{
+    if (!out) return fail(SSAMD_EINVAL, "out is NULL");
+    int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
+    if (rc) return rc;
+    const int nD = maxDisparity - minDisparity + 1;
+    if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
+    AswGeom g;
+    if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
+    out[0] = g.pipe; out[1] = g.Rx; out[2] = g.JC >= winSize ? 0 : g.JC; out[3] = g.pipe ? g.dephase : 0;
+    return SSAMD_OK;
+}
+
 int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
 {
     if (!out) return fail(SSAMD_EINVAL, "out is NULL");
