@@ -462,24 +462,41 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         if (Rx == 4 && nD > 56) continue;
         const int max_wps = Rx == 8 ? 3 : 4;
         const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + Rx - 1) / Rx);
+        const int pipe_env = getenv("SSAMD_ASW_PIPE") ? atoi(getenv("SSAMD_ASW_PIPE")) : -1;
         for (int XG = xg_cap; XG >= 1; --XG)
-        for (int JC : {1 << 20, 16, 8, 4}) {
-            if (JC < (1 << 20) && (JC >= win || JC % Rx)) continue;
+        for (int cand = 0; cand < 6; ++cand) {
+            // candidates 0-3: asw_aggregate_kernel with whole window rows or tap-column chunks of 16 / 8 / 4;
+            // candidates 4-5: the phase-shifted kernel (8-column tile) with chunks of 16 / 8
+            static const int jcs[6] = {1 << 20, 16, 8, 4, 16, 8};
+            const int JC = jcs[cand];
+            const bool piped = cand >= 4;
             AswGeom g;
-            if (!asw_layout(g, win, XG, DG, 160 * 1024, JC, Rx)) continue;
+            if (piped) {
+                if (Rx != 8 || pipe_env == 0 || (pipe_env > 0 && pipe_env != JC)) continue;
+                if (pipe_env < 0 && JC == 8 && round_up(XG * DG, 64) / 64 < 12) continue;      // see asw_try_pipe
+                if (!asw_layout_e(g, win, XG, DG, 160 * 1024, JC, 8, true, false, true)) continue;
+            } else {
+                if (JC < (1 << 20) && (JC >= win || JC % Rx)) continue;
+                if (!asw_layout(g, win, XG, DG, 160 * 1024, JC, Rx)) continue;
+            }
             g.nchunks = nch;
             const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
             const int k = std::min(max_wps / per_simd, (160 * 1024) / g.lds_bytes);
             if (k < 1) continue;
             // per-thread aggregation cycles of one window row; the 4-column tile spends the same address and
-            // e-row work on half the taps
-            const double M = (double)win * Rx * ASW_RD * (Rx == 8 ? c_tap : c_tap * 1.15);
+            // e-row work on half the taps; the phase-shifted kernel's step is 107 instead of 111 instructions
+            // with a third of the bank conflicts
+            const double M = (double)win * Rx * ASW_RD * (Rx == 8 ? (piped ? 0.93 * c_tap : c_tap) : c_tap * 1.15);
             const int ncen = g.Tx + g.nRc;
-            const int njc = (win + g.JC - 1) / g.JC;                 // weight-build passes (= barriers) per window row
-            const double B = (double)njc * ((ncen * g.wseg + g.threads - 1) / g.threads) * (round_up(g.wlen, ASW_WB) + 2) * c_w +
-                             (njc > 1 ? njc * 400.0 : 0.0) +               // extra barriers of the chunked form
-                             (double)((g.nL * (g.Dc / 4) + g.threads - 1) / g.threads) * c_e +
-                             (double)((g.nL + g.nR + g.threads - 1) / g.threads) * c_stage;
+            const int njc = piped ? g.NC : (win + g.JC - 1) / g.JC;     // weight-build passes (= barriers) per window row
+            double B;
+            if (piped)      // no e tiles (TAD volume), one centre per thread, the build partly under other waves' taps
+                B = (double)ncen * win / g.threads * 28.0 + njc * 350.0 + c_stage;
+            else
+                B = (double)njc * ((ncen * g.wseg + g.threads - 1) / g.threads) * (round_up(g.wlen, ASW_WB) + 2) * c_w +
+                    (njc > 1 ? njc * 400.0 : 0.0) +               // extra barriers of the chunked form
+                    (double)((g.nL * (g.Dc / 4) + g.threads - 1) / g.threads) * c_e +
+                    (double)((g.nL + g.nR + g.threads - 1) / g.threads) * c_stage;
             const double d_util = (double)nD / ((double)nch * g.Dc);
             const int xt = (W + g.Tx - 1) / g.Tx;
             const double x_util = (double)W / ((double)xt * g.Tx);
@@ -494,7 +511,7 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             const double score = (double)XG * DG / per_simd * occ * (useful / (M + B)) * d_util * x_util * tail * overlap;
             if (score > best_score) { best_score = score; best = g; found = true; }
             if (shortlist) {
-                auto &slot = classes[{Rx, std::min(g.JC, 64), nch, waves}];
+                auto &slot = classes[{piped ? 80 : Rx, std::min(g.JC, 64), nch, waves}];
                 if (score > slot.first) slot = {score, g};
             }
         }
@@ -505,14 +522,14 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
     // x tiles under long weight rows) staging the tap columns in chunks of 16 is 1-1.5 % FASTER than whole rows --
     // build and aggregation phases of different waves interleave (1080p/193: 46.9 -> 46.2 ms, 4K/257: 271.9 -> 269.2 ms,
     // 1080p/129: 32.4 -> 32.0 ms) -- while for DG <= 25 it is 4-6 % slower, as the model says.
-    if (found && best.Rx == 8 && best.JC >= win && best.DG >= 33 && win > 16) {
+    if (found && !best.pipe && best.Rx == 8 && best.JC >= win && best.DG >= 33 && win > 16) {
         AswGeom g;
         if (asw_layout(g, win, best.XG, best.DG, 160 * 1024, 16, 8)) {
             g.nchunks = best.nchunks;
             best = g;
         }
     }
-    if (found) { asw_pick_e_scheme(best, win); asw_try_pipe(best, win); }
+    if (found && !best.pipe) asw_pick_e_scheme(best, win);      // (the phase-shifted form competed in the search above)
     if (shortlist && found) {
         std::vector<std::pair<double, AswGeom>> v;
         for (auto &kv : classes) v.push_back(kv.second);
@@ -520,11 +537,8 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         shortlist->clear();
         // every class enters in its phase-shifted form where that exists AND in the plain form: which of the two is
         // faster depends on the tile (waves per SIMD, centres per thread), and the trials measure it
-        for (size_t i = 0; i < v.size() && i < 8 && v[i].first > 0.6 * best_score && shortlist->size() < 12; ++i) {
-            asw_pick_e_scheme(v[i].second, win);
-            AswGeom piped = v[i].second;
-            asw_try_pipe(piped, win);
-            if (piped.pipe) shortlist->push_back(piped);
+        for (size_t i = 0; i < v.size() && i < 12 && v[i].first > 0.6 * best_score; ++i) {
+            if (!v[i].second.pipe) asw_pick_e_scheme(v[i].second, win);
             shortlist->push_back(v[i].second);
         }
     }
