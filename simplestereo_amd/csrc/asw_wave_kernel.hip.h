@@ -1,0 +1,283 @@
+// K1w: ASW aggregation for SMALL disparity ranges (the class default maxDisparity = 16; gfx950).
+//
+// Same algebra, same 8 x 4 register tile, same tap order -- therefore the same sums bit for bit -- as
+// asw_aggregate_kernel / asw_aggregate_pipe_kernel; what changes is who builds the support weights.
+//
+// With few disparities the workgroup kernels starve: a tile of Tx columns x Dc disparities has only Tx * Dc / 32
+// threads but needs 2 Tx + Dc weights per tap column in LDS, so at Dc = 20 the double-buffered weight rows allow two
+// 4-wave groups per CU (two waves per SIMD), and 28 % of the instructions are support weights behind barriers
+// (profiles/r02_asw_default_d16_rocprof_summary.txt: 10.1 ms for 1080p / D 0..16 / win 35 against ~4 ms of work).
+//
+// Here a WAVE is the unit.  Its 64 lanes are NXG = 64 / DG column groups x all DG disparity groups of one output row
+// (lane = xg * DG + dg), i.e. a strip of 8 * NXG columns with the whole disparity range.  Per tap column the wave
+//   1. evaluates the 2 * Txw + Dc - 1 support weights its own taps need -- one centre per lane, consecutive lanes
+//      consecutive centres -- into a wave-private LDS row (no redundancy inside the strip: every weight is used by
+//      all of the wave's disparities),
+//   2. runs the 32 taps per lane of that column from it.
+// LDS traffic from one wave is served in order, so step 2 sees step 1 without any workgroup barrier; waves never
+// wait for each other (a workgroup is just four independent waves), and a wave needs ~13 KB of LDS (pixel row,
+// centre pixels, e rows, one weight row), so twelve waves per CU stay resident at 163 VGPRs.
+// e tiles come from the TAD volume of asw_tad_volume_kernel (LDS-DMA, one image row at a time).
+// Used when the whole range fits one chunk of at most 8 disparity groups (nD <= 32).
+#pragma once
+#include "asw_kernels.hip.h"
+
+namespace ssamd {
+
+struct AswWaveGeom {
+    int RX, DG, NXG, Txw, Dc, lanes;        // columns per lane (8 or 4); disparity groups, column groups and columns per wave, lanes in use
+    int nLw, nRcw, nRw;                     // left tap columns, right centres, right tap columns of a wave's strip
+    int SLw, SRw, Se;                       // floats per weight row (left / right part), bytes per e column
+    int waves;                              // waves per workgroup
+    int off_w, off_cen, off_pixL, off_pixR, off_e, off_bestL, off_bestR;     // offsets inside a wave's LDS slice
+    int wave_lds;                           // bytes of LDS per wave
+};
+
+struct AswWaveArgs {
+    const PixRec *recL, *recR;
+    const float *prox;
+    u64 *keyL, *keyR;
+    int16_t *disp;               // non-null: no right-referenced pass -> the wave writes the disparities itself
+    float *costs;                // optional raw cost dump
+    const unsigned char *evol;   // TAD volume (required)
+    int erow0, erows, evolW;
+    int H, W, win, pad, minD, maxD, row0, rows, ystep;
+    float kC;
+    AswWaveGeom g;
+};
+
+// wave-local ordering of LDS traffic: nothing may be moved across by the compiler, everything issued has completed
+__device__ __forceinline__ void asw_wave_sync()
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS instructions of one wave execute in issue order, so a wave's ds_read sees its own earlier ds_write without
+// waiting for it; only the compiler must keep the order.
+__device__ __forceinline__ void asw_wave_order()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool WITH_COSTS, int RX>
+__global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kernel(const AswWaveArgs A)
+{
+    constexpr int NWR = asw_nwr(RX);
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const AswWaveGeom &g = A.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char *const smem = smem_all + wave * g.wave_lds;
+    float *const wS = reinterpret_cast<float *>(smem + g.off_w);            // [SLw + SRw]: left weights, then right weights
+    float4 *const cenLab = reinterpret_cast<float4 *>(smem + g.off_cen);    // [Txw + nRcw]
+    float4 *const pixL = reinterpret_cast<float4 *>(smem + g.off_pixL);     // [nLw] Lab of the current image row
+    float4 *const pixR = reinterpret_cast<float4 *>(smem + g.off_pixR);     // [nRw]
+    unsigned char *const eT = reinterpret_cast<unsigned char *>(smem + g.off_e);   // [nLw][Se]
+    u64 *const bestL = reinterpret_cast<u64 *>(smem + g.off_bestL);
+    u64 *const bestR = reinterpret_cast<u64 *>(smem + g.off_bestR);
+
+    const int W = A.W, win = A.win, p = A.pad;
+    const int Txw = g.Txw, Dc = g.Dc, nLw = g.nLw, nRcw = g.nRcw, nRw = g.nRw, Se = g.Se;
+    const int x0 = (blockIdx.x * g.waves + wave) * Txw;
+    if (x0 >= W) return;                                         // (no workgroup barrier anywhere: waves are independent)
+    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int dlo = A.minD, dhi = dlo + Dc - 1;
+    const size_t orow = (size_t)(y - A.row0) * W;
+    if (min(x0 + Txw - 1, W - 1) - dlo < 0) {                   // no candidate the reference evaluates in this strip
+        if (A.disp)
+            for (int k = lane; k < Txw && x0 + k < W; k += 64) A.disp[orow + x0 + k] = (int16_t)(x0 + k);
+        return;
+    }
+    const int segL_lo = x0 - p, xrc_lo = x0 - dhi, segR_lo = xrc_lo - p;
+    const int ncen = Txw + nRcw;
+    const int xg = lane / g.DG, dg = lane - xg * g.DG;
+    const bool active = lane < g.lanes;
+
+    float accN[RX][ASW_RD], accS[RX][ASW_RD];
+#pragma unroll
+    for (int a = 0; a < RX; ++a)
+#pragma unroll
+        for (int b = 0; b < ASW_RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
+    for (int c = lane; c < ncen; c += 64) {                      // window centres (row y)
+        const bool isL = c < Txw;
+        const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ccol < (unsigned)W) {
+            const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+            v = make_float4(q.L, q.a, q.b, 1.f);
+        }
+        cenLab[c] = v;
+    }
+    // Support weights of one tap column: lane l evaluates the centres l, l + 64, ... of the left and of the right part.
+    // A tap column outside the image carries .w = 0 and so a zero weight; centres outside the image only feed
+    // candidates the winner-take-all never looks at.
+    const float4 *const tapL0 = pixL + lane, *const tapR0 = pixR + lane;
+    const float4 *const cenL0 = cenLab + lane, *const cenR0 = cenLab + Txw + lane;
+    float *const dstL0 = wS + lane, *const dstR0 = wS + g.SLw + lane;
+    // (no lane guards: reads up to 127 entries past a part's end stay inside the wave's LDS slice and the weight rows
+    // are padded to whole rounds, so the surplus lanes of the last round write weights nobody reads)
+    auto weight = [&](const float4 &ce, const float4 &tp, float pj) {
+        const float dL = tp.x - ce.x, da = tp.y - ce.y, db = tp.z - ce.z;
+        const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
+        return pj * __builtin_amdgcn_exp2f(dist * A.kC) * tp.w;
+    };
+    auto build_part = [&](const float4 *tap, const float4 *cen, float *dst, int n, float pj) {
+        for (int k = 0; k < n; k += 128) {               // two rounds per trip: both rounds' reads are in flight together
+            const bool two = k + 64 < n;                 // (wave-uniform)
+            const float4 ce0 = cen[k], tp0 = tap[k], ce1 = cen[k + 64], tp1 = tap[k + 64];
+            asm volatile("" ::"v"(ce0.w), "v"(tp0.w), "v"(ce1.w), "v"(tp1.w));     // keeps the reads ds_read_b128
+            dst[k] = weight(ce0, tp0, pj);
+            if (two) dst[k + 64] = weight(ce1, tp1, pj);
+        }
+    };
+    auto build = [&](int j, float pj) {
+        build_part(tapL0 + j, cenL0, dstL0, Txw, pj);
+        build_part(tapR0 + j, cenR0, dstR0, nRcw, pj);
+    };
+
+    const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
+    for (int i = i_lo; i < i_hi; ++i) {
+        const int r = y - p + i;
+        asw_wave_sync();                 // the previous window row's taps are done with the pixel and e rows
+        // ---- this image row: e tile by LDS-DMA (one contiguous block of the volume), Lab of the tap columns
+        {
+            const unsigned char *const src = A.evol + (((size_t)(r - A.erow0)) * (size_t)A.evolW + x0) * Se;
+            const int bytes = nLw * Se;
+            for (int k = 0; k < bytes; k += 1024)
+                if (k + lane * 16 < bytes)
+                    __builtin_amdgcn_global_load_lds((const void *)(src + k + lane * 16),
+                                                     (__attribute__((address_space(3))) void *)(eT + k), 16, 0, 0);
+            const PixRec *const rowL = A.recL + (size_t)r * W, *const rowR = A.recR + (size_t)r * W;
+            for (int k = lane; k < nLw + nRw; k += 64) {
+                const bool isL = k < nLw;
+                const int idx = isL ? k : k - nLw;
+                const int col = (isL ? segL_lo : segR_lo) + idx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)col < (unsigned)W) {
+                    const PixRec q = (isL ? rowL : rowR)[col];
+                    v = make_float4(q.L, q.a, q.b, 1.f);      // .w: the column is inside the image
+                }
+                (isL ? pixL : pixR)[idx] = v;
+            }
+        }
+        asw_wave_sync();
+        const __attribute__((address_space(4))) float *const proxRow =
+            (const __attribute__((address_space(4))) float *)(A.prox + i * win);      // constant address space: s_load
+
+        // e window: rows ul = RX xg + n of the tile, dword dg
+        const unsigned char *erow = eT + (RX * xg) * Se + 4 * dg;
+        AswRow ew[RX];
+#pragma unroll
+        for (int n = 0; n < RX - 1; ++n) {
+            asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow));
+            erow += Se;
+        }
+        const float *const wlp = wS + RX * xg;
+        const float *const wrp = wS + g.SLw + (RX * xg - ASW_RD * dg + Dc - ASW_RD);
+
+        for (int j0 = 0; j0 < win; j0 += RX) {
+#define SSAMD_WSTEP(JJ)                                                                             \
+    if (j0 + (JJ) < win) {                                                                          \
+        const int j = j0 + (JJ);                                                                    \
+        /* 1. the support weights of tap column j for the strip's centres (_passive.cpp:47-50, 71-74) */ \
+        build(j, proxRow[j]);                                                                       \
+        asw_wave_order();                                                                           \
+        /* 2. the taps of column j */                                                               \
+        if (active) {                                                                               \
+            const uint32_t epk = *reinterpret_cast<const uint32_t *>(erow);                         \
+            erow += Se;                                                                             \
+            float wl[RX], wr[NWR];                                                                  \
+            {                                                                                       \
+                const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                          \
+                wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                             \
+                if constexpr (RX == 8) {                                                            \
+                    const float4 v1 = *reinterpret_cast<const float4 *>(wlp + 4);                  \
+                    wl[RX - 4] = v1.x; wl[RX - 3] = v1.y; wl[RX - 2] = v1.z; wl[RX - 1] = v1.w;     \
+                }                                                                                   \
+                const float4 r0 = *reinterpret_cast<const float4 *>(wrp);                          \
+                const float4 r1 = *reinterpret_cast<const float4 *>(wrp + 4);                      \
+                asm volatile("" ::"v"(r1.w));                                                       \
+                wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                             \
+                wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                             \
+                if constexpr (RX == 8) {                                                            \
+                    const float4 r2 = *reinterpret_cast<const float4 *>(wrp + 8);                  \
+                    asm volatile("" ::"v"(r2.w));                                                   \
+                    wr[NWR - 4] = r2.x; wr[NWR - 3] = r2.y; wr[NWR - 2] = r2.z; wr[NWR - 1] = r2.w; \
+                }                                                                                   \
+            }                                                                                       \
+            _Pragma("unroll") for (int xi = 0; xi < RX; ++xi) {                                     \
+                if (xi == RX - 1) asw_row_unpack(ew[((JJ) + RX - 1) % RX], epk);                    \
+                const AswRow &row_ = ew[((JJ) + xi) % RX];                                          \
+                _Pragma("unroll") for (int di = 0; di < ASW_RD; ++di) {                             \
+                    const float w_ = wl[xi] * wr[xi - di + ASW_RD - 1];                             \
+                    accN[xi][di] = fmaf(w_, row_.e[di], accN[xi][di]);                              \
+                    accS[xi][di] = fmaf(w_, row_.c[di], accS[xi][di]);                              \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+        asw_wave_order();     /* the weight row is rewritten by the next step */                    \
+    }
+            SSAMD_WSTEP(0) SSAMD_WSTEP(1) SSAMD_WSTEP(2) SSAMD_WSTEP(3)
+            if constexpr (RX == 8) { SSAMD_WSTEP(4) SSAMD_WSTEP(5) SSAMD_WSTEP(6) SSAMD_WSTEP(7) }
+#undef SSAMD_WSTEP
+        }
+    }
+
+    // ---- weighted average (_passive.cpp:88) and the two winner-take-all reductions, inside the wave
+    asw_wave_sync();
+    for (int k = lane; k < Txw; k += 64) bestL[k] = KEY_NONE;        // (these share the pixel rows' space)
+    for (int k = lane; k <= nRcw; k += 64) bestR[k] = KEY_NONE;
+    asw_wave_sync();
+    if (active) {
+        u64 diag[RX + ASW_RD - 1];
+#pragma unroll
+        for (int k = 0; k < RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;
+#pragma unroll
+        for (int xi = 0; xi < RX; ++xi) {
+            const int x = x0 + RX * xg + xi;
+            u64 bl = KEY_NONE;
+#pragma unroll
+            for (int di = 0; di < ASW_RD; ++di) {
+                const int d = dlo + ASW_RD * dg + di;
+                const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
+                if (valid) {
+                    float c;
+                    const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
+                    bl = min(bl, hi | (u64)(uint32_t)d);
+                    diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
+                    if (WITH_COSTS)
+                        A.costs[(orow + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                }
+            }
+            if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);
+        }
+        if (A.keyR) {
+            const int base = RX * xg - ASW_RD * dg + Dc - ASW_RD;
+#pragma unroll
+            for (int k = 0; k < RX + ASW_RD - 1; ++k)
+                if (diag[k] != KEY_NONE) atomicMin(&bestR[base + k], diag[k]);
+        }
+    }
+    asw_wave_sync();
+    if (A.disp) {
+        for (int k = lane; k < Txw; k += 64) {
+            const int x = x0 + k;
+            if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
+        }
+        return;
+    }
+    for (int k = lane; k < Txw; k += 64) {
+        const int x = x0 + k;
+        if (x < W && bestL[k] != KEY_NONE) atomicMin(&A.keyL[orow + x], bestL[k]);
+    }
+    if (A.keyR) {
+        for (int k = lane; k < nRcw; k += 64) {
+            const int xr = xrc_lo + k;
+            if ((unsigned)xr < (unsigned)W && bestR[k] != KEY_NONE) atomicMin(&A.keyR[orow + xr], bestR[k]);
+        }
+    }
+}
+
+}  // namespace ssamd

@@ -21,6 +21,7 @@
 #include "../../include/ssamd.h"
 #include "asw_kernels.hip.h"
 #include "asw_pipe_kernel.hip.h"
+#include "asw_wave_kernel.hip.h"
 #include "asw_alt_kernels.hip.h"
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
@@ -615,6 +616,43 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
     return SSAMD_OK;
 }
 
+// Wave-autonomous kernel for small disparity ranges (asw_wave_kernel.hip.h): geometry of one wave's strip and its
+// slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
+static constexpr int ASW_WAVE_MAX_DG = 12;
+bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
+{
+    g.RX = rx;
+    const int p = win / 2;
+    g.DG = (nD + ASW_RD - 1) / ASW_RD;
+    if (g.DG < 1 || g.DG > ASW_WAVE_MAX_DG) return false;
+    g.NXG = 64 / g.DG;
+    g.Txw = rx * g.NXG;
+    g.Dc = ASW_RD * g.DG;
+    g.lanes = g.NXG * g.DG;
+    g.nLw = g.Txw + 2 * p;
+    g.nRcw = g.Txw + g.Dc - 1;
+    g.nRw = g.nRcw + 2 * p;
+    g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
+    g.SRw = round_up(g.nRcw + 1, 64);
+    g.Se = 16 * ((g.DG + 3) / 4);
+    g.waves = 4;
+    // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
+    // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_w = take((size_t)(g.SLw + g.SRw) * 4);
+    g.off_cen = take((size_t)(g.Txw + g.nRcw) * 16);
+    g.off_pixL = take((size_t)g.nLw * 16);
+    g.off_pixR = take((size_t)g.nRw * 16);
+    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(128 + 2 * p) * 16));
+    // the winner arrays are only used after the last window row: they share the pixel rows' space
+    g.off_bestL = g.off_pixL;
+    g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
+    if ((size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8 > off) off = (size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8;
+    g.wave_lds = (int)((off + 15) & ~(size_t)15);
+    return (size_t)g.wave_lds * g.waves <= 160 * 1024;
+}
+
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
                     float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr)
@@ -629,6 +667,64 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     const int p = win / 2, nD = maxD - minD + 1;
     const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
 
+    // Small disparity ranges: the wave-autonomous kernel (asw_wave_kernel.hip.h).  SSAMD_ASW_WAVE=0 disables it.
+    {
+        AswWaveArgs wa;
+        const bool want = !(getenv("SSAMD_ASW_WAVE") && atoi(getenv("SSAMD_ASW_WAVE")) == 0) && !getenv("SSAMD_ASW_GEOM") && !alternate;
+        const int wave_max_nd = getenv("SSAMD_ASW_WAVE_MAXND") ? atoi(getenv("SSAMD_ASW_WAVE_MAXND")) : 32;
+        if (want && nD >= 1 && nD <= wave_max_nd && asw_wave_layout(wa.g, win, nD, getenv("SSAMD_ASW_WAVE_RX") ? atoi(getenv("SSAMD_ASW_WAVE_RX")) : 8)) {
+            const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
+            const int xt = (W + wa.g.Txw - 1) / wa.g.Txw, evolW = xt * wa.g.Txw + 2 * p;
+            const size_t ebytes = (size_t)(r1 - r0) * (size_t)evolW * (size_t)wa.g.Se;
+            if (ebytes <= ((size_t)24 << 30)) {
+                const int grows = alternate ? (rows + 1) / 2 : rows;
+                const bool direct = !consistent && !alternate;
+                if (!direct) {
+                    if ((rc = c.keyL.reserve(nout * 8))) return rc;
+                    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+                }
+                if (consistent) {
+                    if ((rc = c.keyR.reserve(nout * 8))) return rc;
+                    HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+                }
+                if ((rc = c.recL.reserve(npix * sizeof(PixRec)))) return rc;
+                if ((rc = c.recR.reserve(npix * sizeof(PixRec)))) return rc;
+                const float *d_prox = nullptr;
+                if ((rc = get_prox(c, win, gammaP, s, &d_prox))) return rc;
+                if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
+                if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
+                if ((rc = c.evol.reserve(ebytes + 4096))) return rc;
+                {
+                    Timed t(c, s, SSAMD_K_LAB);
+                    const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), 1u);
+                    hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), (size_t)(2 * TADV_COLS + wa.g.Dc) * 4, s,
+                                       (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr, (unsigned char *)c.evol.ptr, W, p, minD,
+                                       wa.g.Dc, wa.g.Se, r0, r1 - r0, evolW);
+                    HIP_TRY(hipGetLastError());
+                }
+                wa.recL = (const PixRec *)c.recL.ptr; wa.recR = (const PixRec *)c.recR.ptr; wa.prox = d_prox;
+                wa.keyL = direct ? nullptr : (u64 *)c.keyL.ptr;
+                wa.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+                wa.disp = direct ? d_disp : nullptr;
+                wa.costs = d_costs;
+                wa.evol = (const unsigned char *)c.evol.ptr; wa.erow0 = r0; wa.erows = r1 - r0; wa.evolW = evolW;
+                wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
+                wa.ystep = alternate ? 2 : 1;
+                wa.kC = (float)(-1.4426950408889634 / gammaC);
+                auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
+                                        : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
+                const int lds = wa.g.wave_lds * wa.g.waves;
+                if ((rc = grant_dyn_lds(c, (const void *)wk, lds))) return rc;
+                {
+                    Timed t(c, s, SSAMD_K_ASW_AGG);
+                    hipLaunchKernelGGL(wk, dim3((xt + wa.g.waves - 1) / wa.g.waves, grows, 1), dim3(64 * wa.g.waves), lds, s, wa);
+                    HIP_TRY(hipGetLastError());
+                }
+                if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
+                return SSAMD_OK;
+            }
+        }
+    }
     // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
     // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
     AswArgs a;

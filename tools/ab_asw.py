@@ -14,6 +14,8 @@ CASES = [  # name, H, W, maxD, minD, win, consistent
     ("c2", 480, 640, 64, 0, 35, False), ("d16", 1080, 1920, 16, 0, 35, False), ("d7", 1080, 1920, 7, 0, 35, False),
     ("d32", 1080, 1920, 32, 0, 35, False), ("d64", 1080, 1920, 64, 0, 35, False), ("d128w21", 1080, 1920, 128, 0, 21, False),
     ("tsu", 288, 384, 16, 0, 15, False), ("d100w17c", 600, 800, 100, 3, 17, True), ("d40w25", 300, 1000, 40, 0, 25, False),
+    ("d16c", 1080, 1920, 16, 0, 35, True), ("d16w11", 1080, 1920, 16, 0, 11, False), ("d3", 1080, 1920, 3, 0, 35, False),
+    ("d24m5c", 500, 777, 24, 5, 21, True), ("d1", 300, 400, 1, 1, 9, True),
 ]
 
 WORKER = r"""
