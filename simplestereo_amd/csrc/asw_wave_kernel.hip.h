@@ -124,12 +124,17 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
         return pj * __builtin_amdgcn_exp2f(dist * A.kC) * tp.w;
     };
     auto build_part = [&](const float4 *tap, const float4 *cen, float *dst, int n, float pj) {
-        for (int k = 0; k < n; k += 128) {               // two rounds per trip: both rounds' reads are in flight together
-            const bool two = k + 64 < n;                 // (wave-uniform)
+        int k = 0;
+        for (; k + 64 < n; k += 128) {                   // two rounds per trip: both rounds' reads are in flight together
             const float4 ce0 = cen[k], tp0 = tap[k], ce1 = cen[k + 64], tp1 = tap[k + 64];
-            asm volatile("" ::"v"(ce0.w), "v"(tp0.w), "v"(ce1.w), "v"(tp1.w));     // keeps the reads ds_read_b128
+            asm volatile("" ::"v"(ce0.w), "v"(tp0.w), "v"(ce1.w), "v"(tp1.w) : "memory");     // also keeps the reads ds_read_b128
             dst[k] = weight(ce0, tp0, pj);
-            if (two) dst[k + 64] = weight(ce1, tp1, pj);
+            dst[k + 64] = weight(ce1, tp1, pj);
+        }
+        if (k < n) {                                     // an odd round (wave-uniform)
+            const float4 ce0 = cen[k], tp0 = tap[k];
+            asm volatile("" ::"v"(ce0.w), "v"(tp0.w) : "memory");
+            dst[k] = weight(ce0, tp0, pj);
         }
     };
     auto build = [&](int j, float pj) {
@@ -138,10 +143,14 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
     };
 
     const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
+    int proxv = 0;
     for (int i = i_lo; i < i_hi; ++i) {
         const int r = y - p + i;
         asw_wave_sync();                 // the previous window row's taps are done with the pixel and e rows
         // ---- this image row: e tile by LDS-DMA (one contiguous block of the volume), Lab of the tap columns
+#ifdef SSAMD_WABLATE_STAGE
+        if (i == i_lo)
+#endif
         {
             const unsigned char *const src = A.evol + (((size_t)(r - A.erow0)) * (size_t)A.evolW + x0) * Se;
             const int bytes = nLw * Se;
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
                 if (k + lane * 16 < bytes)
                     __builtin_amdgcn_global_load_lds((const void *)(src + k + lane * 16),
                                                      (__attribute__((address_space(3))) void *)(eT + k), 16, 0, 0);
+            proxv = __builtin_bit_cast(int, A.prox[i * win + min(lane, win - 1)]);   // lane j: proximity weight of tap column j
             const PixRec *const rowL = A.recL + (size_t)r * W, *const rowR = A.recR + (size_t)r * W;
             for (int k = lane; k < nLw + nRw; k += 64) {
                 const bool isL = k < nLw;
@@ -163,9 +173,6 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
             }
         }
         asw_wave_sync();
-        const __attribute__((address_space(4))) float *const proxRow =
-            (const __attribute__((address_space(4))) float *)(A.prox + i * win);      // constant address space: s_load
-
         // e window: rows ul = RX xg + n of the tile, dword dg
         const unsigned char *erow = eT + (RX * xg) * Se + 4 * dg;
         AswRow ew[RX];
@@ -177,15 +184,26 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
         const float *const wlp = wS + RX * xg;
         const float *const wrp = wS + g.SLw + (RX * xg - ASW_RD * dg + Dc - ASW_RD);
 
+        // (SSAMD_WABLATE_*: phase-ablation builds of tools/build_variants.sh, never defined in the product)
+#ifdef SSAMD_WABLATE_TAPS
+#define SSAMD_WAVE_TAPS_IF if (i == i_lo && j0 == 0)
+#else
+#define SSAMD_WAVE_TAPS_IF
+#endif
+#ifdef SSAMD_WABLATE_BUILD
+#define SSAMD_WAVE_BUILD(J) if (i == i_lo && (J) == 0) build(J, __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, J)));
+#else
+#define SSAMD_WAVE_BUILD(J) build(J, __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, J)));
+#endif
         for (int j0 = 0; j0 < win; j0 += RX) {
 #define SSAMD_WSTEP(JJ)                                                                             \
     if (j0 + (JJ) < win) {                                                                          \
         const int j = j0 + (JJ);                                                                    \
         /* 1. the support weights of tap column j for the strip's centres (_passive.cpp:47-50, 71-74) */ \
-        build(j, proxRow[j]);                                                                       \
+        SSAMD_WAVE_BUILD(j)                                                                         \
         asw_wave_order();                                                                           \
-        /* 2. the taps of column j */                                                               \
-        if (active) {                                                                               \
+        /* 2. the taps of column j (lanes past the last column group read inside the slice and are ignored) */ \
+        SSAMD_WAVE_TAPS_IF {                                                                        \
             const uint32_t epk = *reinterpret_cast<const uint32_t *>(erow);                         \
             erow += Se;                                                                             \
             float wl[RX], wr[NWR];                                                                  \
@@ -222,6 +240,8 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
             SSAMD_WSTEP(0) SSAMD_WSTEP(1) SSAMD_WSTEP(2) SSAMD_WSTEP(3)
             if constexpr (RX == 8) { SSAMD_WSTEP(4) SSAMD_WSTEP(5) SSAMD_WSTEP(6) SSAMD_WSTEP(7) }
 #undef SSAMD_WSTEP
+#undef SSAMD_WAVE_BUILD
+#undef SSAMD_WAVE_TAPS_IF
         }
     }
 

@@ -634,7 +634,10 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
     g.nRw = g.nRcw + 2 * p;
     g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
     g.SRw = round_up(g.nRcw + 1, 64);
-    g.Se = 16 * ((g.DG + 3) / 4);
+    // bytes per e column: an odd number of dwords, so that the e dwords the lanes of a wave read in one step (column
+    // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
+    // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
+    g.Se = 4 * (g.DG | 1);
     g.waves = 4;
     // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
     // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
@@ -644,7 +647,7 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
     g.off_cen = take((size_t)(g.Txw + g.nRcw) * 16);
     g.off_pixL = take((size_t)g.nLw * 16);
     g.off_pixR = take((size_t)g.nRw * 16);
-    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(128 + 2 * p) * 16));
+    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(128 + 2 * p) * 16) + (size_t)rx * g.Se);
     // the winner arrays are only used after the last window row: they share the pixel rows' space
     g.off_bestL = g.off_pixL;
     g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
@@ -672,9 +675,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         AswWaveArgs wa;
         const bool want = !(getenv("SSAMD_ASW_WAVE") && atoi(getenv("SSAMD_ASW_WAVE")) == 0) && !getenv("SSAMD_ASW_GEOM") && !alternate;
         const int wave_max_nd = getenv("SSAMD_ASW_WAVE_MAXND") ? atoi(getenv("SSAMD_ASW_WAVE_MAXND")) : 32;
-        if (want && nD >= 1 && nD <= wave_max_nd && asw_wave_layout(wa.g, win, nD, getenv("SSAMD_ASW_WAVE_RX") ? atoi(getenv("SSAMD_ASW_WAVE_RX")) : 8)) {
+        if (want && nD >= 1 && nD <= wave_max_nd && win <= 63 && asw_wave_layout(wa.g, win, nD, getenv("SSAMD_ASW_WAVE_RX") ? atoi(getenv("SSAMD_ASW_WAVE_RX")) : 8)) {
             const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
-            const int xt = (W + wa.g.Txw - 1) / wa.g.Txw, evolW = xt * wa.g.Txw + 2 * p;
+            const int xt = (W + wa.g.Txw - 1) / wa.g.Txw, evolW = round_up(xt * wa.g.Txw + 2 * p, 4);   // rows stay 16-byte aligned
             const size_t ebytes = (size_t)(r1 - r0) * (size_t)evolW * (size_t)wa.g.Se;
             if (ebytes <= ((size_t)24 << 30)) {
                 const int grows = alternate ? (rows + 1) / 2 : rows;
