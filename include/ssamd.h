@@ -198,7 +198,9 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
 /* Which form of the ASW aggregation kernel that geometry runs: out[0] = 1 for the phase-shifted kernel
  * (asw_aggregate_pipe_kernel: lanes along the disparity groups, pre-computed TAD volume), 0 for asw_aggregate_kernel;
  * out[1] = columns of the register tile (8 or 4); out[2] = tap columns per chunk (0: whole window rows);
- * out[3] = 1 when waves 0-3 build before they aggregate. */
+ * out[3] = 1 when waves 0-3 build before they aggregate; out[4] = 8 or 4 when asw_aggregate_wave_kernel (small disparity
+ * ranges: every wave builds the support weights of its own strip) runs with that many columns per lane, else 0.
+ * out must hold 5 ints. */
 int ssamd_asw_kernel_form(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
 
 /* Same for a GSW problem; out[0..8] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y,

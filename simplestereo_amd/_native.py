@@ -38,6 +38,14 @@ def lib():
             "simplestereo_amd: native library %s is missing. Build it with "
             "`python -m simplestereo_amd.build` (needs hipcc, targets gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  When torch is importable it goes
+    # first, so libssamd's DT_NEEDED libamdhip64 resolves to the copy torch already loaded (same SONAME) and device
+    # tensors, streams and this library share a runtime; loaded the other way round, whichever runtime initialises
+    # second sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     I, D, F, P = ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_void_p
     L.ssamd_abi_version.restype = I
@@ -112,9 +120,9 @@ def asw_geometry(width, rows, winSize, maxDisparity, minDisparity):
 
 
 def asw_kernel_form(width, rows, winSize, maxDisparity, minDisparity):
-    out = (ctypes.c_int * 4)()
+    out = (ctypes.c_int * 5)()
     check(lib().ssamd_asw_kernel_form(width, rows, winSize, maxDisparity, minDisparity, out))
-    return dict(zip(("phase_shifted", "tile_columns", "chunk_columns", "build_first_waves"), list(out)))
+    return dict(zip(("phase_shifted", "tile_columns", "chunk_columns", "build_first_waves", "wave_kernel"), list(out)))
 
 
 def gsw_geometry(width, rows, winSize, maxDisparity, minDisparity):

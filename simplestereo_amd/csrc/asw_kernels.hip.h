@@ -55,6 +55,8 @@ struct AswGeom {
     int pipe;                    // 1: asw_aggregate_pipe_kernel (asw_pipe_kernel.hip.h): phase-shifted build / aggregation
     int NC, JCmax;               //    chunks per window row (tail shorter than 8 merged into the last) and rows per weight buffer
     int dephase;                 //    1: waves 0-3 build before they aggregate, the others after (0: all after)
+    int wave_rx;                 // 8 or 4: asw_aggregate_wave_kernel (asw_wave_kernel.hip.h) with that many columns per lane runs
+                                 //    instead (small disparity ranges); the other fields then describe the fallback geometry
     int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
 };

@@ -61,8 +61,14 @@ __device__ __forceinline__ void asw_wave_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef SSAMD_WAVE4_OCC          // experiment builds (tools/build_variants.sh): waves per SIMD of the 4-column tile,
+#define SSAMD_WAVE4_OCC 4        // and whether its build keeps two rounds' reads in flight
+#endif
+#ifndef SSAMD_WAVE4_PAIR
+#define SSAMD_WAVE4_PAIR 1
+#endif
 template <bool WITH_COSTS, int RX>
-__global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kernel(const AswWaveArgs A)
+__global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggregate_wave_kernel(const AswWaveArgs A)
 {
     constexpr int NWR = asw_nwr(RX);
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -113,9 +119,14 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
     // Support weights of one tap column: lane l evaluates the centres l, l + 64, ... of the left and of the right part.
     // A tap column outside the image carries .w = 0 and so a zero weight; centres outside the image only feed
     // candidates the winner-take-all never looks at.
-    const float4 *const tapL0 = pixL + lane, *const tapR0 = pixR + lane;
-    const float4 *const cenL0 = cenLab + lane, *const cenR0 = cenLab + Txw + lane;
-    float *const dstL0 = wS + lane, *const dstR0 = wS + g.SLw + lane;
+    // Addresses are LDS byte offsets = a wave-uniform base (SGPR) + the lane's 16 * lane or 4 * lane: the only vector
+    // registers the build keeps between steps are those two (pointers per array would not fit next to the accumulators).
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f *lds_v4;
+    typedef __attribute__((address_space(3))) float *lds_f1;
+    auto ld4 = [](uint32_t a) { const v4f v = *(lds_v4)a; return make_float4(v.x, v.y, v.z, v.w); };
+    const uint32_t sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const uint32_t lane16 = lane * 16, lane4 = lane * 4;
     // (no lane guards: reads up to 127 entries past a part's end stay inside the wave's LDS slice and the weight rows
     // are padded to whole rounds, so the surplus lanes of the last round write weights nobody reads)
     auto weight = [&](const float4 &ce, const float4 &tp, float pj) {
@@ -123,23 +134,35 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
         const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
         return pj * __builtin_amdgcn_exp2f(dist * A.kC) * tp.w;
     };
-    auto build_part = [&](const float4 *tap, const float4 *cen, float *dst, int n, float pj) {
+    // Two tap columns (j, j + 1) per build: a centre is read once for both, and the wave pays the LDS round trip of a
+    // build once per two aggregation steps.  Weight row q = column parity, at wS + q * wrow.
+    const int wrow = g.SLw + g.SRw;
+    auto build_part = [&](uint32_t tap_b, uint32_t cen_b, uint32_t dst_b, int n, float pj0, float pj1) {
+        asm volatile("" : "+s"(tap_b), "+s"(cen_b), "+s"(dst_b));        // opaque: base + lane sums are formed here, per build
+        const uint32_t row1 = (uint32_t)wrow * 4;
         int k = 0;
-        for (; k + 64 < n; k += 128) {                   // two rounds per trip: both rounds' reads are in flight together
-            const float4 ce0 = cen[k], tp0 = tap[k], ce1 = cen[k + 64], tp1 = tap[k + 64];
-            asm volatile("" ::"v"(ce0.w), "v"(tp0.w), "v"(ce1.w), "v"(tp1.w) : "memory");     // also keeps the reads ds_read_b128
-            dst[k] = weight(ce0, tp0, pj);
-            dst[k + 64] = weight(ce1, tp1, pj);
+        // 4-column tile: two rounds per trip, all six reads in flight together (the 8-column tile has no registers for that)
+        if constexpr (RX == 4 && SSAMD_WAVE4_PAIR) for (; k + 64 < n; k += 128) {
+            const uint32_t ca = cen_b + lane16 + k * 16, ta = tap_b + lane16 + k * 16, da = dst_b + lane4 + k * 4;
+            const float4 ce0 = ld4(ca), ta0 = ld4(ta), tb0 = ld4(ta + 16);
+            const float4 ce1 = ld4(ca + 1024), ta1 = ld4(ta + 1024), tb1 = ld4(ta + 1040);
+            asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w), "v"(ce1.w), "v"(ta1.w), "v"(tb1.w) : "memory");   // also keeps the reads ds_read_b128
+            *(lds_f1)da = weight(ce0, ta0, pj0);
+            *(lds_f1)(da + 256) = weight(ce1, ta1, pj0);
+            *(lds_f1)(da + row1) = weight(ce0, tb0, pj1);
+            *(lds_f1)(da + row1 + 256) = weight(ce1, tb1, pj1);
         }
-        if (k < n) {                                     // an odd round (wave-uniform)
-            const float4 ce0 = cen[k], tp0 = tap[k];
-            asm volatile("" ::"v"(ce0.w), "v"(tp0.w) : "memory");
-            dst[k] = weight(ce0, tp0, pj);
+        for (; k < n; k += 64) {                         // single rounds
+            const uint32_t ca = cen_b + lane16 + k * 16, ta = tap_b + lane16 + k * 16, da = dst_b + lane4 + k * 4;
+            const float4 ce0 = ld4(ca), ta0 = ld4(ta), tb0 = ld4(ta + 16);
+            asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w) : "memory");
+            *(lds_f1)da = weight(ce0, ta0, pj0);
+            *(lds_f1)(da + row1) = weight(ce0, tb0, pj1);
         }
     };
-    auto build = [&](int j, float pj) {
-        build_part(tapL0 + j, cenL0, dstL0, Txw, pj);
-        build_part(tapR0 + j, cenR0, dstR0, nRcw, pj);
+    auto build = [&](int j, float pj0, float pj1) {
+        build_part(sbase + g.off_pixL + 16 * j, sbase + g.off_cen, sbase + g.off_w, Txw, pj0, pj1);
+        build_part(sbase + g.off_pixR + 16 * j, sbase + g.off_cen + 16 * Txw, sbase + g.off_w + 4 * g.SLw, nRcw, pj0, pj1);
     };
 
     const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
@@ -191,36 +214,39 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
 #define SSAMD_WAVE_TAPS_IF
 #endif
 #ifdef SSAMD_WABLATE_BUILD
-#define SSAMD_WAVE_BUILD(J) if (i == i_lo && (J) == 0) build(J, __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, J)));
+#define SSAMD_WAVE_BUILD(J) if (i == i_lo && (J) == 0) build(J, __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, J)), \
+                                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, (J) + 1)));
 #else
-#define SSAMD_WAVE_BUILD(J) build(J, __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, J)));
+#define SSAMD_WAVE_BUILD(J) build(J, __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, J)), \
+                                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(proxv, (J) + 1)));
 #endif
         for (int j0 = 0; j0 < win; j0 += RX) {
 #define SSAMD_WSTEP(JJ)                                                                             \
     if (j0 + (JJ) < win) {                                                                          \
         const int j = j0 + (JJ);                                                                    \
-        /* 1. the support weights of tap column j for the strip's centres (_passive.cpp:47-50, 71-74) */ \
-        SSAMD_WAVE_BUILD(j)                                                                         \
+        /* 1. even j: the support weights of tap columns j, j + 1 for the strip's centres (_passive.cpp:47-50, 71-74) */ \
+        if (((JJ) & 1) == 0) { SSAMD_WAVE_BUILD(j) }                                                \
         asw_wave_order();                                                                           \
+        const float *const wl_ = wlp + ((JJ) & 1) * wrow, *const wr_ = wrp + ((JJ) & 1) * wrow;     \
         /* 2. the taps of column j (lanes past the last column group read inside the slice and are ignored) */ \
         SSAMD_WAVE_TAPS_IF {                                                                        \
             const uint32_t epk = *reinterpret_cast<const uint32_t *>(erow);                         \
             erow += Se;                                                                             \
             float wl[RX], wr[NWR];                                                                  \
             {                                                                                       \
-                const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                          \
+                const float4 v0 = *reinterpret_cast<const float4 *>(wl_);                          \
                 wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                             \
                 if constexpr (RX == 8) {                                                            \
-                    const float4 v1 = *reinterpret_cast<const float4 *>(wlp + 4);                  \
+                    const float4 v1 = *reinterpret_cast<const float4 *>(wl_ + 4);                  \
                     wl[RX - 4] = v1.x; wl[RX - 3] = v1.y; wl[RX - 2] = v1.z; wl[RX - 1] = v1.w;     \
                 }                                                                                   \
-                const float4 r0 = *reinterpret_cast<const float4 *>(wrp);                          \
-                const float4 r1 = *reinterpret_cast<const float4 *>(wrp + 4);                      \
+                const float4 r0 = *reinterpret_cast<const float4 *>(wr_);                          \
+                const float4 r1 = *reinterpret_cast<const float4 *>(wr_ + 4);                      \
                 asm volatile("" ::"v"(r1.w));                                                       \
                 wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                             \
                 wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                             \
                 if constexpr (RX == 8) {                                                            \
-                    const float4 r2 = *reinterpret_cast<const float4 *>(wrp + 8);                  \
+                    const float4 r2 = *reinterpret_cast<const float4 *>(wr_ + 8);                  \
                     asm volatile("" ::"v"(r2.w));                                                   \
                     wr[NWR - 4] = r2.x; wr[NWR - 3] = r2.y; wr[NWR - 2] = r2.z; wr[NWR - 1] = r2.w; \
                 }                                                                                   \
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : 5) void asw_aggregate_wave_kerne
                 }                                                                                   \
             }                                                                                       \
         }                                                                                           \
-        asw_wave_order();     /* the weight row is rewritten by the next step */                    \
+        asw_wave_order();     /* the weight rows are rewritten by the next even step */             \
     }
             SSAMD_WSTEP(0) SSAMD_WSTEP(1) SSAMD_WSTEP(2) SSAMD_WSTEP(3)
             if constexpr (RX == 8) { SSAMD_WSTEP(4) SSAMD_WSTEP(5) SSAMD_WSTEP(6) SSAMD_WSTEP(7) }

@@ -245,7 +245,7 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
 {
     g.Rx = Rx;
     g.JC = JC >= win ? win : JC;                 // tap columns staged per chunk; win = the whole row at once
-    g.pipe = 0; g.NC = 1; g.JCmax = g.JC; g.dephase = 0;
+    g.pipe = 0; g.NC = 1; g.JCmax = g.JC; g.dephase = 0; g.wave_rx = 0;
     if (pipe) {
         // phase-shifted kernel (asw_pipe_kernel.hip.h): chunks start at multiples of JC (8 or 16), a tail shorter than
         // the 8-column register tile is merged into the last chunk; needs >= 2 chunks, two e tiles, the 8-column tile
@@ -393,6 +393,67 @@ void asw_try_pipe(AswGeom &g, int win)
     }
 }
 
+// Wave-autonomous kernel for small disparity ranges (asw_wave_kernel.hip.h): geometry of one wave's strip and its
+// slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
+static constexpr int ASW_WAVE_MAX_DG = 12;
+bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
+{
+    g.RX = rx;
+    const int p = win / 2;
+    g.DG = (nD + ASW_RD - 1) / ASW_RD;
+    if (g.DG < 1 || g.DG > ASW_WAVE_MAX_DG) return false;
+    g.NXG = 64 / g.DG;
+    g.Txw = rx * g.NXG;
+    g.Dc = ASW_RD * g.DG;
+    g.lanes = g.NXG * g.DG;
+    g.nLw = g.Txw + 2 * p;
+    g.nRcw = g.Txw + g.Dc - 1;
+    g.nRw = g.nRcw + 2 * p;
+    g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
+    g.SRw = round_up(g.nRcw + 1, 64);
+    // bytes per e column: an odd number of dwords, so that the e dwords the lanes of a wave read in one step (column
+    // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
+    // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
+    g.Se = 4 * (g.DG | 1);
+    g.waves = 4;
+    // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
+    // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_w = take((size_t)(g.SLw + g.SRw) * 4 * 2);        // two rows: tap columns j and j + 1
+    g.off_cen = take((size_t)(g.Txw + g.nRcw) * 16);
+    g.off_pixL = take((size_t)g.nLw * 16);
+    g.off_pixR = take((size_t)g.nRw * 16);
+    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(129 + 2 * p) * 16) + (size_t)rx * g.Se);
+    // the winner arrays are only used after the last window row: they share the pixel rows' space
+    g.off_bestL = g.off_pixL;
+    g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
+    if ((size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8 > off) off = (size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8;
+    g.wave_lds = (int)((off + 15) & ~(size_t)15);
+    return (size_t)g.wave_lds * g.waves <= 160 * 1024;
+}
+
+// Which wave kernel (0: none) serves a window / disparity range.  Measured on 1080p and VGA frames, windows 11..35
+// (profiles/r02_wave_sweep.txt): the wave kernel beats the workgroup kernels up to 48 disparities; the 4-column tile
+// (more waves per SIMD, half the LDS per wave) wins up to 16 disparities, the 8-column tile above.
+// SSAMD_ASW_WAVE=0 disables it, SSAMD_ASW_WAVE_RX=8|4 forces a tile (experiments / tests); SSAMD_ASW_EVOL=0 (in-kernel e
+// tiles) also disables it, the wave kernel needs the TAD volume.
+static constexpr int ASW_WAVE_MAX_ND = 48;
+int asw_wave_pick(int win, int nD)
+{
+    if (getenv("SSAMD_ASW_WAVE") && atoi(getenv("SSAMD_ASW_WAVE")) == 0) return 0;
+    if (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0) return 0;
+    if (nD < 1 || nD > ASW_WAVE_MAX_ND || win > 63) return 0;
+    AswWaveGeom wg;
+    if (const char *env = getenv("SSAMD_ASW_WAVE_RX")) {
+        const int rx = atoi(env);
+        return (rx == 8 || rx == 4) && asw_wave_layout(wg, win, nD, rx) ? rx : 0;
+    }
+    const int first = nD <= 16 ? 4 : 8, second = 12 - first;
+    if (asw_wave_layout(wg, win, nD, first)) return first;
+    return asw_wave_layout(wg, win, nD, second) ? second : 0;
+}
+
 // Pick the workgroup tile (XG column groups x DG disparity groups, nchunks disparity chunks)
 // with an occupancy-aware cost model calibrated on MI355X (profiles/r01_*):
 //   - the kernel needs 168 VGPRs -> 3 waves per SIMD; a workgroup of w waves puts ceil(w/4)
@@ -414,9 +475,12 @@ std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached
 std::atomic<int> g_autotune{getenv("SSAMD_AUTOTUNE") ? (atoi(getenv("SSAMD_AUTOTUNE")) > 0 ? 1 : (atoi(getenv("SSAMD_AUTOTUNE")) < 0 ? -1 : 0)) : -1};
 constexpr double ASW_AUTOTUNE_SMALL_TAPS = 3.0e10;      // window taps per call (about 3-4 ms of kernel time)
 
+// experiment / test hooks that force a kernel form: such calls neither read nor write the geometry cache and are not autotuned
+bool asw_geometry_forced() { return getenv("SSAMD_ASW_GEOM") || getenv("SSAMD_ASW_WAVE") || getenv("SSAMD_ASW_WAVE_RX"); }
+
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
-    if (getenv("SSAMD_ASW_GEOM")) return asw_search_geometry(best, W, rows, win, nD);      // tuning hook: never cached
+    if (asw_geometry_forced()) return asw_search_geometry(best, W, rows, win, nD);          // tuning hooks: never cached
     std::lock_guard<std::mutex> glk(g_geom_mutex);
     const std::array<int, 4> key{W, rows, win, nD};
     auto it = g_asw_geom_cache.find(key);
@@ -531,15 +595,28 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         }
     }
     if (found && !best.pipe) asw_pick_e_scheme(best, win);      // (the phase-shifted form competed in the search above)
+    // small disparity ranges: the wave kernel takes over (the workgroup geometry stays as its fallback)
+    const int wave_rx = found ? asw_wave_pick(win, nD) : 0;
+    if (wave_rx) best.wave_rx = wave_rx;
     if (shortlist && found) {
         std::vector<std::pair<double, AswGeom>> v;
         for (auto &kv : classes) v.push_back(kv.second);
         std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         shortlist->clear();
+        if (wave_rx) {          // the model's choice first, then the other tile of the wave kernel, then workgroup geometries
+            shortlist->push_back(best);
+            AswWaveGeom wg;
+            if (!getenv("SSAMD_ASW_WAVE_RX") && asw_wave_layout(wg, win, nD, 12 - wave_rx)) {
+                AswGeom other = best;
+                other.wave_rx = 12 - wave_rx;
+                shortlist->push_back(other);
+            }
+        }
         // every class enters in its phase-shifted form where that exists AND in the plain form: which of the two is
         // faster depends on the tile (waves per SIMD, centres per thread), and the trials measure it
         for (size_t i = 0; i < v.size() && i < 12 && v[i].first > 0.6 * best_score; ++i) {
             if (!v[i].second.pipe) asw_pick_e_scheme(v[i].second, win);
+            v[i].second.wave_rx = 0;
             shortlist->push_back(v[i].second);
         }
     }
@@ -616,46 +693,6 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
     return SSAMD_OK;
 }
 
-// Wave-autonomous kernel for small disparity ranges (asw_wave_kernel.hip.h): geometry of one wave's strip and its
-// slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
-static constexpr int ASW_WAVE_MAX_DG = 12;
-bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
-{
-    g.RX = rx;
-    const int p = win / 2;
-    g.DG = (nD + ASW_RD - 1) / ASW_RD;
-    if (g.DG < 1 || g.DG > ASW_WAVE_MAX_DG) return false;
-    g.NXG = 64 / g.DG;
-    g.Txw = rx * g.NXG;
-    g.Dc = ASW_RD * g.DG;
-    g.lanes = g.NXG * g.DG;
-    g.nLw = g.Txw + 2 * p;
-    g.nRcw = g.Txw + g.Dc - 1;
-    g.nRw = g.nRcw + 2 * p;
-    g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
-    g.SRw = round_up(g.nRcw + 1, 64);
-    // bytes per e column: an odd number of dwords, so that the e dwords the lanes of a wave read in one step (column
-    // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
-    // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
-    g.Se = 4 * (g.DG | 1);
-    g.waves = 4;
-    // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
-    // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    g.off_w = take((size_t)(g.SLw + g.SRw) * 4);
-    g.off_cen = take((size_t)(g.Txw + g.nRcw) * 16);
-    g.off_pixL = take((size_t)g.nLw * 16);
-    g.off_pixR = take((size_t)g.nRw * 16);
-    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(128 + 2 * p) * 16) + (size_t)rx * g.Se);
-    // the winner arrays are only used after the last window row: they share the pixel rows' space
-    g.off_bestL = g.off_pixL;
-    g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
-    if ((size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8 > off) off = (size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8;
-    g.wave_lds = (int)((off + 15) & ~(size_t)15);
-    return (size_t)g.wave_lds * g.waves <= 160 * 1024;
-}
-
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
                     float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr)
@@ -670,64 +707,6 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     const int p = win / 2, nD = maxD - minD + 1;
     const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
 
-    // Small disparity ranges: the wave-autonomous kernel (asw_wave_kernel.hip.h).  SSAMD_ASW_WAVE=0 disables it.
-    {
-        AswWaveArgs wa;
-        const bool want = !(getenv("SSAMD_ASW_WAVE") && atoi(getenv("SSAMD_ASW_WAVE")) == 0) && !getenv("SSAMD_ASW_GEOM") && !alternate;
-        const int wave_max_nd = getenv("SSAMD_ASW_WAVE_MAXND") ? atoi(getenv("SSAMD_ASW_WAVE_MAXND")) : 32;
-        if (want && nD >= 1 && nD <= wave_max_nd && win <= 63 && asw_wave_layout(wa.g, win, nD, getenv("SSAMD_ASW_WAVE_RX") ? atoi(getenv("SSAMD_ASW_WAVE_RX")) : 8)) {
-            const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
-            const int xt = (W + wa.g.Txw - 1) / wa.g.Txw, evolW = round_up(xt * wa.g.Txw + 2 * p, 4);   // rows stay 16-byte aligned
-            const size_t ebytes = (size_t)(r1 - r0) * (size_t)evolW * (size_t)wa.g.Se;
-            if (ebytes <= ((size_t)24 << 30)) {
-                const int grows = alternate ? (rows + 1) / 2 : rows;
-                const bool direct = !consistent && !alternate;
-                if (!direct) {
-                    if ((rc = c.keyL.reserve(nout * 8))) return rc;
-                    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
-                }
-                if (consistent) {
-                    if ((rc = c.keyR.reserve(nout * 8))) return rc;
-                    HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
-                }
-                if ((rc = c.recL.reserve(npix * sizeof(PixRec)))) return rc;
-                if ((rc = c.recR.reserve(npix * sizeof(PixRec)))) return rc;
-                const float *d_prox = nullptr;
-                if ((rc = get_prox(c, win, gammaP, s, &d_prox))) return rc;
-                if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
-                if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
-                if ((rc = c.evol.reserve(ebytes + 4096))) return rc;
-                {
-                    Timed t(c, s, SSAMD_K_LAB);
-                    const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), 1u);
-                    hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), (size_t)(2 * TADV_COLS + wa.g.Dc) * 4, s,
-                                       (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr, (unsigned char *)c.evol.ptr, W, p, minD,
-                                       wa.g.Dc, wa.g.Se, r0, r1 - r0, evolW);
-                    HIP_TRY(hipGetLastError());
-                }
-                wa.recL = (const PixRec *)c.recL.ptr; wa.recR = (const PixRec *)c.recR.ptr; wa.prox = d_prox;
-                wa.keyL = direct ? nullptr : (u64 *)c.keyL.ptr;
-                wa.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
-                wa.disp = direct ? d_disp : nullptr;
-                wa.costs = d_costs;
-                wa.evol = (const unsigned char *)c.evol.ptr; wa.erow0 = r0; wa.erows = r1 - r0; wa.evolW = evolW;
-                wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
-                wa.ystep = alternate ? 2 : 1;
-                wa.kC = (float)(-1.4426950408889634 / gammaC);
-                auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
-                                        : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
-                const int lds = wa.g.wave_lds * wa.g.waves;
-                if ((rc = grant_dyn_lds(c, (const void *)wk, lds))) return rc;
-                {
-                    Timed t(c, s, SSAMD_K_ASW_AGG);
-                    hipLaunchKernelGGL(wk, dim3((xt + wa.g.waves - 1) / wa.g.waves, grows, 1), dim3(64 * wa.g.waves), lds, s, wa);
-                    HIP_TRY(hipGetLastError());
-                }
-                if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
-                return SSAMD_OK;
-            }
-        }
-    }
     // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
     // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
     AswArgs a;
@@ -743,11 +722,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     const bool tune_now = tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS);
     bool tuned_already;
     { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_asw_geom_tuned.count(shape) != 0; }
-    if (tune_now && nD >= 1 && !getenv("SSAMD_ASW_GEOM") && !tuned_already) {
+    if (tune_now && nD >= 1 && !asw_geometry_forced() && !tuned_already) {
         AswGeom tmp;
         if (asw_search_geometry(tmp, W, grows, win, nD, &trial) != SSAMD_OK || trial.size() < 2) trial.clear();
     }
-    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && g.nchunks == 1 && !consistent; };
+    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent; };
     bool need_keys = !is_direct(a.g) || alternate;  // the alternate mode merges its odd-row jobs through the left keys
     for (const AswGeom &g : trial) need_keys = need_keys || !is_direct(g);
     if (need_keys) {
@@ -778,22 +757,32 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.evol = nullptr; a.erow0 = r0; a.erows = r1 - r0; a.evolW = 0;
         // pre-computed truncated-absolute-difference volume for the phase-shifted kernel (asw_tad_volume_kernel);
         // SSAMD_ASW_EVOL=0 keeps the in-kernel e tiles (experiments / tests)
+        AswWaveArgs wa;
         auto prepare_evol = [&](const AswGeom &g) -> int {
             a.evol = nullptr;
-            if (!g.pipe || (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0)) return SSAMD_OK;
-            const int xt = (W + g.Tx - 1) / g.Tx;
-            const int evolW = xt * g.Tx + 2 * p;
-            const size_t bytes = (size_t)g.nchunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)g.Se;
-            if (bytes > ((size_t)24 << 30)) return SSAMD_OK;          // very large frames: build the tiles in the kernel
+            int chunks = g.nchunks, Tx = g.Tx, Dc = g.Dc, Se = g.Se;
+            if (g.wave_rx) {
+                if (!asw_wave_layout(wa.g, win, nD, g.wave_rx)) return fail(SSAMD_ELIMIT, "wave kernel geometry does not fit LDS");
+                chunks = 1; Tx = wa.g.Txw; Dc = wa.g.Dc; Se = wa.g.Se;
+            } else if (!g.pipe || (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0)) {
+                return SSAMD_OK;
+            }
+            const int xt = (W + Tx - 1) / Tx;
+            const int evolW = round_up(xt * Tx + 2 * p, 4);           // rows stay 16-byte aligned for any Se
+            const size_t bytes = (size_t)chunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)Se;
+            if (bytes > ((size_t)24 << 30)) {
+                if (g.wave_rx) return fail(SSAMD_ELIMIT, "TAD volume of %zu bytes is too large", bytes);
+                return SSAMD_OK;                                      // very large frames: build the tiles in the kernel
+            }
             int erc = c.evol.reserve(bytes + 4096);                     // + one DMA piece of slack behind the last tile
             if (erc) return erc;
             a.evol = (const unsigned char *)c.evol.ptr;
             a.evolW = evolW;
             Timed t(c, s, SSAMD_K_LAB);
-            const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), (unsigned)g.nchunks);
-            const size_t elds = (size_t)(2 * TADV_COLS + g.Dc) * 4;
+            const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), (unsigned)chunks);
+            const size_t elds = (size_t)(2 * TADV_COLS + Dc) * 4;
             hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), elds, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
-                               (unsigned char *)c.evol.ptr, W, p, minD, g.Dc, g.Se, r0, r1 - r0, evolW);
+                               (unsigned char *)c.evol.ptr, W, p, minD, Dc, Se, r0, r1 - r0, evolW);
             HIP_TRY(hipGetLastError());
             return SSAMD_OK;
         };
@@ -801,6 +790,20 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.g = g;
             a.keyL = is_direct(g) ? nullptr : (u64 *)c.keyL.ptr;
             a.disp = is_direct(g) ? d_disp : nullptr;
+            if (g.wave_rx) {                  // (prepare_evol(g) filled wa.g and built the volume)
+                wa.recL = a.recL; wa.recR = a.recR; wa.prox = a.prox;
+                wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs;
+                wa.evol = a.evol; wa.erow0 = a.erow0; wa.erows = a.erows; wa.evolW = a.evolW;
+                wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
+                wa.ystep = a.ystep; wa.kC = a.kC;
+                auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
+                                       : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
+                const int lds = wa.g.wave_lds * wa.g.waves, xt = (W + wa.g.Txw - 1) / wa.g.Txw;
+                if (int grc = grant_dyn_lds(c, (const void *)wk, lds)) return grc;
+                hipLaunchKernelGGL(wk, dim3((xt + wa.g.waves - 1) / wa.g.waves, grows, 1), dim3(64 * wa.g.waves), lds, s, wa);
+                HIP_TRY(hipGetLastError());
+                return SSAMD_OK;
+            }
             const dim3 grid((W + g.Tx - 1) / g.Tx, grows, g.nchunks), block(g.threads);
             const bool chunked = g.JC < win;
             if (g.pipe) {
@@ -1232,6 +1235,11 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
     if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
     out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
     out[5] = (width + g.Tx - 1) / g.Tx; out[6] = rows; out[7] = g.nchunks;
+    AswWaveGeom wg;
+    if (g.wave_rx && asw_wave_layout(wg, winSize, nD, g.wave_rx)) {      // a "tile" = the four strips of a workgroup's waves
+        out[0] = wg.Txw * wg.waves; out[1] = wg.Dc; out[2] = 1; out[3] = 64 * wg.waves; out[4] = wg.wave_lds * wg.waves;
+        out[5] = (width + out[0] - 1) / out[0]; out[7] = 1;
+    }
     return SSAMD_OK;
 }
 
@@ -1245,6 +1253,8 @@ int ssamd_asw_kernel_form(int width, int rows, int winSize, int maxDisparity, in
     AswGeom g;
     if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
     out[0] = g.pipe; out[1] = g.Rx; out[2] = g.JC >= winSize ? 0 : g.JC; out[3] = g.pipe ? g.dephase : 0;
+    out[4] = g.wave_rx;
+    if (g.wave_rx) { out[0] = 0; out[1] = g.wave_rx; out[2] = 0; out[3] = 0; }
     return SSAMD_OK;
 }
 

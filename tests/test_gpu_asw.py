@@ -200,6 +200,77 @@ def test_asw_phase_shifted_kernel_equals_the_plain_one(geom, win, ss, golden_inp
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("win,maxd,mind,consistent", [(35, 16, 0, False), (35, 16, 0, True), (21, 7, 0, True), (9, 3, 0, False),
+                                                       (15, 1, 1, True), (1, 12, 0, True), (5, 47, 0, True), (17, 36, 5, True),
+                                                       (11, 23, 9, True), (63, 20, 2, False)])
+def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consistent, ss, golden_inputs):
+    """asw_aggregate_wave_kernel (small disparity ranges: a wave builds the support weights of its own strip, no
+    workgroup barriers) accumulates the same taps in the same order as the workgroup kernels: with both register tiles
+    forced, for ranges of 1..48 disparities, windows 1..63, minDisparity 0 and above, image widths that end
+    inside a strip and images narrower than one strip, the maps -- consistent mode: both argmins, and the raw cost
+    dump -- are those of the workgroup kernel bit for bit.  The class default (maxDisparity 16) runs this kernel."""
+    from simplestereo_amd import _native
+    a, b = golden_inputs("synth_96x128")
+    pairs = [(a, b), (np.ascontiguousarray(a[:50, :77]), np.ascontiguousarray(b[:50, :77])),
+             (np.ascontiguousarray(a[:40, :23]), np.ascontiguousarray(b[:40, :23]))]
+    nD = maxd - mind + 1
+    assert _native.asw_kernel_form(1920, 1080, win, maxd, mind)["wave_kernel"] in (4, 8)
+    assert _native.asw_kernel_form(1920, 1080, 35, 16, 0)["wave_kernel"] == 8          # class default range
+    assert _native.asw_kernel_form(1920, 1080, 35, 64, 0)["wave_kernel"] == 0
+    m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, minDisparity=mind, consistent=consistent, gammaC=6.0)
+
+    def run(L, R):
+        H, W = L.shape[:2]
+        c = np.empty((H, W, nD), np.float32)
+        _native.check(_native.lib().ssamd_asw_costs(L.ctypes.data, R.ctypes.data, H, W, win, maxd, mind, 6.0, 17.5, c.ctypes.data, -1))
+        return m.compute(L, R), c
+    try:
+        os.environ["SSAMD_ASW_WAVE"] = "0"
+        want = [run(L, R) for L, R in pairs]
+        os.environ["SSAMD_ASW_WAVE"] = "1"
+        ran = 0
+        for rx in ("8", "4"):
+            os.environ["SSAMD_ASW_WAVE_RX"] = rx
+            if _native.asw_kernel_form(128, 96, win, maxd, mind)["wave_kernel"] != int(rx):
+                continue                                      # this tile does not fit LDS for the window / range
+            ran += 1
+            for (L, R), (wd, wc) in zip(pairs, want):
+                gd, gc = run(L, R)
+                assert np.array_equal(gd, wd), (rx, L.shape)
+                assert np.array_equal(gc, wc, equal_nan=True), (rx, L.shape)
+        assert ran >= 1
+    finally:
+        for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX"):
+            os.environ.pop(k, None)
+
+
+def test_asw_wave_kernel_strips_and_alternate_rows(ss, golden_inputs):
+    """the wave kernel under the other entry points: a row strip with its halo equals the rows of the whole frame, the
+    alternate-rows mode and the separate argmins equal those computed with the workgroup kernels"""
+    from simplestereo_amd import _native
+    import torch
+    a, b = golden_inputs("synth_96x128")
+    tL, tR = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    m = ss.passive.StereoASW(winSize=13, maxDisparity=16, consistent=True)
+    alt = ss.passive.StereoASW(winSize=13, maxDisparity=16, alternate=True)
+    try:
+        os.environ["SSAMD_ASW_WAVE"] = "0"
+        want, want_alt = m.compute(tL, tR), alt.compute(tL, tR)
+        want_strip = m._compute_device(tL[20:70].contiguous(), tR[20:70].contiguous(), out_row0=6, out_rows=38)
+        os.environ["SSAMD_ASW_WAVE"] = "1"
+        for rx in ("8", "4"):
+            os.environ["SSAMD_ASW_WAVE_RX"] = rx
+            assert _native.asw_kernel_form(128, 96, 13, 16, 0)["wave_kernel"] == int(rx)
+            assert torch.equal(m.compute(tL, tR), want)
+            assert torch.equal(alt.compute(tL, tR), want_alt)
+            got_strip = m._compute_device(tL[20:70].contiguous(), tR[20:70].contiguous(), out_row0=6, out_rows=38)
+            assert torch.equal(got_strip, want_strip)
+            assert torch.equal(got_strip, want[26:64])
+    finally:
+        for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX"):
+            os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("H,W,maxd,shift", [(1080, 1920, 192, 150), (2160, 4096, 256, 233)])
 def test_asw_full_size_configs_3_and_5_known_shift_and_strip_invariance(H, W, maxd, shift, ss):
     """BASELINE configs 3 and 5 at full size, through size-independent properties: (1) a right image that is the

@@ -52,6 +52,10 @@ def main():
     only = [a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")]
     if only:
         cases = [c for c in CASES if c[0] in only[0]]
+    for a in sys.argv[1:]:
+        if a.startswith("--cases="):          # --cases=name:H:W:maxD:minD:win:consistent(0/1),...
+            cases = [(f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), bool(int(f[6])))
+                     for f in (c.split(":") for c in a.split("=", 1)[1].split(","))]
     variants = []
     for a in args or ["base"]:
         name, _, envs = a.partition("=")
