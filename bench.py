@@ -53,6 +53,7 @@ CONFIGS = {
     "c2_480p_d64_w35": (480, 640, 64, 0, 35),
     "c5_4k_d256_w35": (2160, 4096, 256, 0, 35),
     "default_1080p_d16_w35": (1080, 1920, 16, 0, 35),      # StereoASW() class defaults (passive.py:59) on a 1080p frame
+    "small_1080p_d7_w35": (1080, 1920, 7, 0, 35),          # an even smaller range: the support weights dominate
 }
 GSW_CONFIGS = {
     # BASELINE config 4: StereoGSW class defaults (winSize 11, gamma 10, fMax 120, iterations 3) at 1080p / D 0..192
@@ -239,7 +240,8 @@ def others(dev, seed):
         return cache[(H, W, maxD)]
 
     jobs = [("c3_1080p_d192_w35_consistent", "c3_1080p_d192_w35", True), ("c2_480p_d64_w35", "c2_480p_d64_w35", False),
-            ("default_1080p_d16_w35", "default_1080p_d16_w35", False), ("c5_4k_d256_w35_1gpu", "c5_4k_d256_w35", False)]
+            ("default_1080p_d16_w35", "default_1080p_d16_w35", False), ("small_1080p_d7_w35", "small_1080p_d7_w35", False),
+            ("c5_4k_d256_w35_1gpu", "c5_4k_d256_w35", False)]
     for name, cfgname, consistent in jobs:
         try:
             H, W, maxD, minD, win = CONFIGS[cfgname]
@@ -252,7 +254,8 @@ def others(dev, seed):
             res[name] = {"matcher": "StereoASW", "H": H, "W": W, "maxDisparity": maxD, "minDisparity": minD, "winSize": win,
                          "consistent": consistent, "ms_per_step": wall, "value": H * W * nD / (wall * 1e-3) / 1e6,
                          "unit": "MPixels*disp/s", "kernel_ms": k_ms, "taps": taps, "checksum": checksum,
-                         "valu_frac": VALU_OPS_PER_TAP * taps / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None}
+                         "valu_frac": VALU_OPS_PER_TAP * taps / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None,
+                         "kernel_form": _native.asw_kernel_form(W, H, win, maxD, minD)}
         except Exception as e:      # noqa: BLE001
             res[name] = {"error": repr(e)[:200]}
     for name, (H, W, maxD, minD, win) in GSW_CONFIGS.items():

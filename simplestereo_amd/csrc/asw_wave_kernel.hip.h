@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
         cenLab[c] = v;
     }
     // Support weights of one tap column: lane l evaluates the centres l, l + 64, ... of the left and of the right part.
-    // A tap column outside the image carries .w = 0 and so a zero weight; centres outside the image only feed
-    // candidates the winner-take-all never looks at.
+    // A tap column outside the image has L = +inf and so a zero weight; centres outside the image only feed candidates
+    // the winner-take-all never looks at.
     // Addresses are LDS byte offsets = a wave-uniform base (SGPR) + the lane's 16 * lane or 4 * lane: the only vector
     // registers the build keeps between steps are those two (pointers per array would not fit next to the accumulators).
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
     auto weight = [&](const float4 &ce, const float4 &tp, float pj) {
         const float dL = tp.x - ce.x, da = tp.y - ce.y, db = tp.z - ce.z;
         const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
-        return pj * __builtin_amdgcn_exp2f(dist * A.kC) * tp.w;
+        return pj * __builtin_amdgcn_exp2f(dist * A.kC);
     };
     // Two tap columns (j, j + 1) per build: a centre is read once for both, and the wave pays the LDS round trip of a
     // build once per two aggregation steps.  Weight row q = column parity, at wS + q * wrow.
@@ -187,10 +187,12 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
                 const bool isL = k < nLw;
                 const int idx = isL ? k : k - nLw;
                 const int col = (isL ? segL_lo : segR_lo) + idx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                // a tap column outside the image gets L = +inf: its colour distance is +inf, exp2(-inf) = +0 and the
+                // weight is exactly the +0 the other kernels produce with a mask, without an instruction for it
+                float4 v = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);
                 if ((unsigned)col < (unsigned)W) {
                     const PixRec q = (isL ? rowL : rowR)[col];
-                    v = make_float4(q.L, q.a, q.b, 1.f);      // .w: the column is inside the image
+                    v = make_float4(q.L, q.a, q.b, 0.f);
                 }
                 (isL ? pixL : pixR)[idx] = v;
             }
