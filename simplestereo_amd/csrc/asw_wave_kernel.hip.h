@@ -227,8 +227,7 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
     if (j0 + (JJ) < win) {                                                                          \
         const int j = j0 + (JJ);                                                                    \
         /* 1. even j: the support weights of tap columns j, j + 1 for the strip's centres (_passive.cpp:47-50, 71-74) */ \
-        if (((JJ) & 1) == 0) { SSAMD_WAVE_BUILD(j) }                                                \
-        asw_wave_order();                                                                           \
+        if (((JJ) & 1) == 0) { asw_wave_order(); SSAMD_WAVE_BUILD(j) asw_wave_order(); }           \
         const float *const wl_ = wlp + ((JJ) & 1) * wrow, *const wr_ = wrp + ((JJ) & 1) * wrow;     \
         /* 2. the taps of column j (lanes past the last column group read inside the slice and are ignored) */ \
         SSAMD_WAVE_TAPS_IF {                                                                        \
@@ -263,7 +262,6 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
                 }                                                                                   \
             }                                                                                       \
         }                                                                                           \
-        asw_wave_order();     /* the weight rows are rewritten by the next even step */             \
     }
             SSAMD_WSTEP(0) SSAMD_WSTEP(1) SSAMD_WSTEP(2) SSAMD_WSTEP(3)
             if constexpr (RX == 8) { SSAMD_WSTEP(4) SSAMD_WSTEP(5) SSAMD_WSTEP(6) SSAMD_WSTEP(7) }
