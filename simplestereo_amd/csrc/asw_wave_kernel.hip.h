@@ -21,6 +21,7 @@
 // Used when the whole range fits one chunk of at most 8 disparity groups (nD <= 32).
 #pragma once
 #include "asw_kernels.hip.h"
+#include <type_traits>
 
 namespace ssamd {
 
@@ -67,7 +68,9 @@ __device__ __forceinline__ void asw_wave_order()
 #ifndef SSAMD_WAVE4_PAIR
 #define SSAMD_WAVE4_PAIR 1
 #endif
-template <bool WITH_COSTS, int RX>
+// KL, KR: build rounds (64 centres each) of the left and of the right part when the host knows them at compile time
+// (the build is then straight-line code with immediate offsets); 0: counted at run time.
+template <bool WITH_COSTS, int RX, int KL = 0, int KR = 0>
 __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggregate_wave_kernel(const AswWaveArgs A)
 {
     constexpr int NWR = asw_nwr(RX);
@@ -137,9 +140,34 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
     // Two tap columns (j, j + 1) per build: a centre is read once for both, and the wave pays the LDS round trip of a
     // build once per two aggregation steps.  Weight row q = column parity, at wS + q * wrow.
     const int wrow = g.SLw + g.SRw;
-    auto build_part = [&](uint32_t tap_b, uint32_t cen_b, uint32_t dst_b, int n, float pj0, float pj1) {
+    auto build_part = [&](auto rounds, uint32_t tap_b, uint32_t cen_b, uint32_t dst_b, int n, float pj0, float pj1) {
         asm volatile("" : "+s"(tap_b), "+s"(cen_b), "+s"(dst_b));        // opaque: base + lane sums are formed here, per build
         const uint32_t row1 = (uint32_t)wrow * 4;
+        constexpr int K = decltype(rounds)::value;
+        if constexpr (K > 0) {                           // round count known: one address per array, immediate offsets
+            const uint32_t ca = cen_b + lane16, ta = tap_b + lane16, da = dst_b + lane4, db_ = da + row1;
+            if constexpr (RX == 4 && K <= 3) {           // registers to spare: all reads of the part in flight together
+                float4 ce[K], ta_[K], tb[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) { ce[r] = ld4(ca + 1024 * r); ta_[r] = ld4(ta + 1024 * r); tb[r] = ld4(ta + 1024 * r + 16); }
+#pragma unroll
+                for (int r = 0; r < K; ++r) asm volatile("" ::"v"(ce[r].w), "v"(ta_[r].w), "v"(tb[r].w) : "memory");
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    *(lds_f1)(da + 256 * r) = weight(ce[r], ta_[r], pj0);
+                    *(lds_f1)(db_ + 256 * r) = weight(ce[r], tb[r], pj1);
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const float4 ce0 = ld4(ca + 1024 * r), ta0 = ld4(ta + 1024 * r), tb0 = ld4(ta + 1024 * r + 16);
+                asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w));   // keeps the reads ds_read_b128
+                *(lds_f1)(da + 256 * r) = weight(ce0, ta0, pj0);
+                *(lds_f1)(db_ + 256 * r) = weight(ce0, tb0, pj1);
+            }
+            return;
+        }
         int k = 0;
         // 4-column tile: two rounds per trip, all six reads in flight together (the 8-column tile has no registers for that)
         if constexpr (RX == 4 && SSAMD_WAVE4_PAIR) for (; k + 64 < n; k += 128) {
@@ -161,8 +189,9 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
         }
     };
     auto build = [&](int j, float pj0, float pj1) {
-        build_part(sbase + g.off_pixL + 16 * j, sbase + g.off_cen, sbase + g.off_w, Txw, pj0, pj1);
-        build_part(sbase + g.off_pixR + 16 * j, sbase + g.off_cen + 16 * Txw, sbase + g.off_w + 4 * g.SLw, nRcw, pj0, pj1);
+        build_part(std::integral_constant<int, KL>{}, sbase + g.off_pixL + 16 * j, sbase + g.off_cen, sbase + g.off_w, Txw, pj0, pj1);
+        build_part(std::integral_constant<int, KR>{}, sbase + g.off_pixR + 16 * j, sbase + g.off_cen + 16 * Txw, sbase + g.off_w + 4 * g.SLw,
+                   nRcw, pj0, pj1);
     };
 
     const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);

@@ -798,6 +798,17 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 wa.ystep = a.ystep; wa.kC = a.kC;
                 auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
                                        : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
+                // build rounds known at compile time (straight-line build): the common combinations
+                const int kl = (wa.g.Txw + 63) / 64, kr = (wa.g.nRcw + 63) / 64;
+                const bool unrolled = !(getenv("SSAMD_ASW_WAVE_UNROLL") && atoi(getenv("SSAMD_ASW_WAVE_UNROLL")) == 0);
+                if (unrolled && !d_costs) {
+                    const int key = wa.g.RX * 100 + kl * 10 + kr;
+                    if (key == 822) wk = asw_aggregate_wave_kernel<false, 8, 2, 2>;         // 17..28 disparities (class default)
+                    else if (key == 812) wk = asw_aggregate_wave_kernel<false, 8, 1, 2>;    // 29..48
+                    else if (key == 412) wk = asw_aggregate_wave_kernel<false, 4, 1, 2>;    // 13..20
+                    else if (key == 422) wk = asw_aggregate_wave_kernel<false, 4, 2, 2>;    // 9..12
+                    else if (key == 423) wk = asw_aggregate_wave_kernel<false, 4, 2, 3>;    // 5..8
+                }
                 const int lds = wa.g.wave_lds * wa.g.waves, xt = (W + wa.g.Txw - 1) / wa.g.Txw;
                 if (int grc = grant_dyn_lds(c, (const void *)wk, lds)) return grc;
                 hipLaunchKernelGGL(wk, dim3((xt + wa.g.waves - 1) / wa.g.waves, grows, 1), dim3(64 * wa.g.waves), lds, s, wa);
