@@ -415,7 +415,7 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
     // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
     // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
     g.Se = 4 * (g.DG | 1);
-    g.waves = 4;
+    g.waves = getenv("SSAMD_ASW_WAVE_WG") ? std::max(1, std::min(4, atoi(getenv("SSAMD_ASW_WAVE_WG")))) : 1;
     // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
     // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
     size_t off = 0;
