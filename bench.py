@@ -403,7 +403,10 @@ def main():
                        "launch": geom, "checksum": checksum},
             # the bound that binds: fp32 VALU issue (no MFMA on this path, as north_star prescribes; HBM is ~3 orders
             # of magnitude away, kept as roofline.hbm because north_star names it)
-            "roofline": {"bound": "valu", "kernel": "asw_aggregate_kernel", "achieved": achieved_ops, "peak": VALU_PEAK_LANEOPS,
+            "roofline": {"bound": "valu",
+                         "kernel": ("asw_aggregate_wave_kernel" if geom.get("wave_kernel") else
+                                    "asw_aggregate_pipe_kernel" if geom.get("phase_shifted") else "asw_aggregate_kernel"),
+                         "achieved": achieved_ops, "peak": VALU_PEAK_LANEOPS,
                          "unit": "lane-ops/s", "frac": (achieved_ops / VALU_PEAK_LANEOPS) if achieved_ops else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": k_ms, "launches": launches[_native.K_ASW_AGG],
