@@ -68,10 +68,13 @@ __device__ __forceinline__ void asw_wave_order()
 #ifndef SSAMD_WAVE4_PAIR
 #define SSAMD_WAVE4_PAIR 1
 #endif
+#ifndef SSAMD_WAVE8_OCC
+#define SSAMD_WAVE8_OCC 3
+#endif
 // KL, KR: build rounds (64 centres each) of the left and of the right part when the host knows them at compile time
 // (the build is then straight-line code with immediate offsets); 0: counted at run time.
 template <bool WITH_COSTS, int RX, int KL = 0, int KR = 0>
-__global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggregate_wave_kernel(const AswWaveArgs A)
+__global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) void asw_aggregate_wave_kernel(const AswWaveArgs A)
 {
     constexpr int NWR = asw_nwr(RX);
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, RX == 8 ? 3 : SSAMD_WAVE4_OCC) void asw_aggreg
         constexpr int K = decltype(rounds)::value;
         if constexpr (K > 0) {                           // round count known: one address per array, immediate offsets
             const uint32_t ca = cen_b + lane16, ta = tap_b + lane16, da = dst_b + lane4, db_ = da + row1;
-            if constexpr (RX == 4 && K <= 3) {           // registers to spare: all reads of the part in flight together
+            if constexpr ((RX == 4 || SSAMD_WAVE8_OCC == 2) && K <= 3) {           // registers to spare: all reads of the part in flight together
                 float4 ce[K], ta_[K], tb[K];
 #pragma unroll
                 for (int r = 0; r < K; ++r) { ce[r] = ld4(ca + 1024 * r); ta_[r] = ld4(ta + 1024 * r); tb[r] = ld4(ta + 1024 * r + 16); }
