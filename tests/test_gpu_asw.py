@@ -244,6 +244,29 @@ def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consisten
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("maxd,win", [(7, 35), (16, 35), (39, 21)])
+def test_asw_wave_kernel_full_width_rows(maxd, win, ss):
+    """1920-column rows (20 strips of 96 columns / 15 of 128 / 34 of 56 plus a ragged last one; waves per workgroup 1, 2
+    and 4): both tiles of the wave kernel give the map of the workgroup kernels bit for bit"""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(44, 1920, maxd, 11)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, consistent=True)
+    try:
+        os.environ["SSAMD_ASW_WAVE"] = "0"
+        want = m.compute(tL, tR)
+        os.environ["SSAMD_ASW_WAVE"] = "1"
+        for rx, wg in (("8", "1"), ("4", "1"), ("8", "4"), ("4", "2")):
+            os.environ["SSAMD_ASW_WAVE_RX"], os.environ["SSAMD_ASW_WAVE_WG"] = rx, wg
+            assert torch.equal(m.compute(tL, tR), want), (rx, wg)
+        os.environ["SSAMD_ASW_WAVE_UNROLL"] = "0"
+        assert torch.equal(m.compute(tL, tR), want)
+    finally:
+        for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL"):
+            os.environ.pop(k, None)
+
+
 def test_asw_wave_kernel_strips_and_alternate_rows(ss, golden_inputs):
     """the wave kernel under the other entry points: a row strip with its halo equals the rows of the whole frame, the
     alternate-rows mode and the separate argmins equal those computed with the workgroup kernels"""
