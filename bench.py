@@ -50,6 +50,7 @@ if ROOT not in sys.path:
 CONFIGS = {
     # name: (H, W, maxDisparity, minDisparity, winSize)
     "c3_1080p_d192_w35": (1080, 1920, 192, 0, 35),
+    "c1_tsukuba_d16_w15": (288, 384, 16, 0, 15),           # BASELINE config 1: the reference's own example size (synthetic pair here)
     "c2_480p_d64_w35": (480, 640, 64, 0, 35),
     "c5_4k_d256_w35": (2160, 4096, 256, 0, 35),
     "default_1080p_d16_w35": (1080, 1920, 16, 0, 35),      # StereoASW() class defaults (passive.py:59) on a 1080p frame
@@ -239,7 +240,8 @@ def others(dev, seed):
             cache[(H, W, maxD)] = (torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev))
         return cache[(H, W, maxD)]
 
-    jobs = [("c3_1080p_d192_w35_consistent", "c3_1080p_d192_w35", True), ("c2_480p_d64_w35", "c2_480p_d64_w35", False),
+    jobs = [("c3_1080p_d192_w35_consistent", "c3_1080p_d192_w35", True), ("c1_tsukuba_d16_w15", "c1_tsukuba_d16_w15", False),
+            ("c2_480p_d64_w35", "c2_480p_d64_w35", False),
             ("default_1080p_d16_w35", "default_1080p_d16_w35", False), ("small_1080p_d7_w35", "small_1080p_d7_w35", False),
             ("c5_4k_d256_w35_1gpu", "c5_4k_d256_w35", False)]
     for name, cfgname, consistent in jobs:
