@@ -614,7 +614,8 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         }
         // every class enters in its phase-shifted form where that exists AND in the plain form: which of the two is
         // faster depends on the tile (waves per SIMD, centres per thread), and the trials measure it
-        for (size_t i = 0; i < v.size() && i < 12 && v[i].first > 0.6 * best_score; ++i) {
+        // (next to the wave kernel only the three best workgroup classes: they have not won a trial for such ranges)
+        for (size_t i = 0; i < v.size() && i < (wave_rx ? 3u : 12u) && v[i].first > 0.6 * best_score; ++i) {
             if (!v[i].second.pipe) asw_pick_e_scheme(v[i].second, win);
             v[i].second.wave_rx = 0;
             shortlist->push_back(v[i].second);
