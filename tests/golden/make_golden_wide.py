@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors at the HEADLINE launch geometries, from the UNMODIFIED reference (oracle/_ref).
 
-    make -C oracle ref && python tests/golden/make_golden_wide.py        (build container only; ~6 min on 8 cores)
+    make -C oracle ref && python tests/golden/make_golden_wide.py [--only-new]       (build container only; ~6 min on 8 cores)
 
 tests/golden/cases.npz stops at 640x480 / D 0..64.  The bench line and BASELINE configs 3, 4 and 5 run 1920- and
 4096-wide frames with 193 / 257 disparities, i.e. other workgroup tiles, chunkings and key paths of the kernels.
@@ -41,6 +41,11 @@ CASES = {
     # config 4: GSW class defaults, 1920 wide, D 0..192 (left-right check always on)
     "W4a": (1080, 1920, 192, 0, 520, 40, G(winSize=11, maxDisparity=192, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
     "W4b": (1080, 1920, 192, 1, 520, 40, G(winSize=11, maxDisparity=192, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
+    # small disparity ranges on frames whose true disparities lie in the range (the wave kernel's 4- and 8-column tiles):
+    # D 0..7, the class default D 0..16 with the left-right check, D 3..40 with a 21 x 21 window
+    "W3d": (1080, 1920, 7, 2, 520, 40, A(winSize=35, maxDisparity=7, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True)),
+    "W3e": (1080, 1920, 16, 4, 520, 40, A(winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True)),
+    "W3f": (1080, 1920, 40, 3, 520, 44, A(winSize=21, maxDisparity=40, minDisparity=3, gammaC=5, gammaP=17.5, consistent=True)),
 }
 
 
@@ -54,7 +59,14 @@ def main():
     if ref is None:
         raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` first")
     maps, meta = {}, {}
+    only_new = "--only-new" in sys.argv          # keep the cases already in wide_cases.npz, compute the ones added since
+    if only_new:
+        old = np.load(os.path.join(OUT, "wide_cases.npz"))
+        maps = {k: old[k] for k in old.files}
+        meta = json.load(open(os.path.join(OUT, "wide_cases.json")))
     for cid, (H, W, maxD, seed, r0, rows, p) in CASES.items():
+        if only_new and cid in maps:
+            continue
         a, b = strip_inputs(H, W, maxD, seed, r0, rows)
         t = time.time()
         if p["algo"] == "asw":

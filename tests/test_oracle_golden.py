@@ -99,7 +99,7 @@ def test_consistent_map_is_lr_check_and_fill_of_the_two_argmins(inp, p, golden_i
     assert np.array_equal(lr_check_fill_literal(left, right), oracle.asw(a, b, consistent=True, **p))
 
 
-@pytest.mark.parametrize("cid", ["W3c", "W4a"])
+@pytest.mark.parametrize("cid", ["W3c", "W3d", "W4a"])
 def test_oracle_on_headline_width_strips(cid):
     """the C restatement (hoisted / closed-form modes) against the reference's maps of full-width strips of the
     config-3 / config-4 frames (tests/golden/wide_cases.npz): 1920 columns, the class-default range D 0..16 win 35
