@@ -1417,7 +1417,9 @@ int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const flo
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const long long npix = (long long)dst_h * dst_w;
-    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 16);
+    // (a thread owns four output pixels; the map and output pointers are 16- / 4-byte aligned: device allocations)
+    if (((uintptr_t)d_mapx | (uintptr_t)d_mapy) & 15 || ((uintptr_t)d_dst & 3)) return fail(SSAMD_EINVAL, "maps must be 16-byte and the output 4-byte aligned");
+    const int blocks = (int)std::min<long long>((npix / 4 + 255) / 256 + 1, 256 * 16);
     Timed t(*c, s, SSAMD_K_REMAP);
     hipLaunchKernelGGL(remap_bgr_kernel, dim3(blocks), dim3(256), 0, s, d_src, src_h, src_w, d_mapx, d_mapy, d_dst, npix,
                        interpolation == 0 ? 1 : 0);

@@ -78,6 +78,33 @@ def test_remap_kernel_rounds_ties_up_like_opencv_fixed_point(env):
     assert np.array_equal(got, _rigs._remap(img, mx, my))
 
 
+@pytest.mark.parametrize("shape", [(7, 9, 5, 11), (33, 21, 40, 37), (1, 1, 3, 2), (16, 16, 16, 16)])
+def test_remap_kernel_odd_sizes_borders_and_last_pixels(shape, env):
+    """outputs whose pixel count is not a multiple of the four pixels a thread owns, maps that point outside the source
+    on every side and exactly at its last pixels (the 8-byte source reads must not leave the buffer): equal to the oracle"""
+    ss, torch, rig = env
+    import ctypes
+    from oracle import rig_oracle
+    from simplestereo_amd import _native
+    hs, ws, hd, wd = shape
+    rng = np.random.default_rng(hs * 100 + wd)
+    img = rng.integers(0, 256, (hs, ws, 3)).astype(np.uint8)
+    mx = rng.uniform(-2.5, ws + 1.5, (hd, wd)).astype(np.float32)
+    my = rng.uniform(-2.5, hs + 1.5, (hd, wd)).astype(np.float32)
+    mx.flat[0], my.flat[0] = ws - 1, hs - 1                      # the very last source pixel
+    mx.flat[-1], my.flat[-1] = ws - 1.5, hs - 1.5                # the 2 x 2 block that ends the buffer
+    if mx.size > 2:
+        mx.flat[1], my.flat[1] = ws - 2.0, hs - 1.0              # last row, last pixel pair
+    t = torch.from_numpy(img).cuda()
+    dmx, dmy = torch.from_numpy(mx).cuda(), torch.from_numpy(my).cuda()
+    for interp in (1, 0):
+        out = torch.empty((hd, wd, 3), dtype=torch.uint8, device="cuda")
+        _native.check(_native.lib().ssamd_remap_bgr_device(t.data_ptr(), hs, ws, dmx.data_ptr(), dmy.data_ptr(), hd, wd, interp,
+                                                           out.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        want = rig_oracle.remap_bilinear(img, mx, my, nearest=(interp == 0))
+        assert np.array_equal(out.cpu().numpy(), want), (shape, interp)
+
+
 def test_reproject_kernel_vs_oracle_and_host_path(env):
     ss, torch, rig = env
     from oracle import rig_oracle
