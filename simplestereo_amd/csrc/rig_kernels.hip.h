@@ -88,22 +88,46 @@ struct Mat4 {
     double m[16];
 };
 
-// [X Y Z W]^T = Q [x y d 1]^T ; point = (X/W, Y/W, Z/W) as float32
+// [X Y Z W]^T = Q [x y d 1]^T ; point = (X/W, Y/W, Z/W) as float32.  Grid row = image row: no 64-bit division / modulo
+// per pixel.  With W a multiple of 4 a thread owns four pixels: one 8-byte disparity read, three 16-byte stores.
+__device__ __forceinline__ void reproject_pixel(const Mat4 &Q, double x, double y, double d, float &ox, float &oy, float &oz)
+{
+    const double X = Q.m[0] * x + Q.m[1] * y + Q.m[2] * d + Q.m[3];
+    const double Y = Q.m[4] * x + Q.m[5] * y + Q.m[6] * d + Q.m[7];
+    const double Z = Q.m[8] * x + Q.m[9] * y + Q.m[10] * d + Q.m[11];
+    const double Wc = Q.m[12] * x + Q.m[13] * y + Q.m[14] * d + Q.m[15];
+    ox = (float)(X / Wc);
+    oy = (float)(Y / Wc);
+    oz = (float)(Z / Wc);
+}
+
 __global__ __launch_bounds__(256) void reproject_kernel(const int16_t *__restrict__ disp, float *__restrict__ pts,
                                                         int H, int W, const Mat4 Q)
 {
-    const long long npix = (long long)H * W;
-    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; p < npix; p += stride) {
-        const double x = (double)(p % W), y = (double)(p / W), d = (double)disp[p];
-        const double X = Q.m[0] * x + Q.m[1] * y + Q.m[2] * d + Q.m[3];
-        const double Y = Q.m[4] * x + Q.m[5] * y + Q.m[6] * d + Q.m[7];
-        const double Z = Q.m[8] * x + Q.m[9] * y + Q.m[10] * d + Q.m[11];
-        const double Wc = Q.m[12] * x + Q.m[13] * y + Q.m[14] * d + Q.m[15];
-        pts[3 * p] = (float)(X / Wc);
-        pts[3 * p + 1] = (float)(Y / Wc);
-        pts[3 * p + 2] = (float)(Z / Wc);
+    const int y = blockIdx.y;
+    const double yd = (double)y;
+    const int16_t *const drow = disp + (size_t)y * W;
+    float *const prow = pts + (size_t)y * W * 3;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if ((W & 3) == 0) {
+        for (int q = t; 4 * q < W; q += nt) {
+            const short4 dv = reinterpret_cast<const short4 *>(drow)[q];
+            float o[12];
+            reproject_pixel(Q, (double)(4 * q), yd, (double)dv.x, o[0], o[1], o[2]);
+            reproject_pixel(Q, (double)(4 * q + 1), yd, (double)dv.y, o[3], o[4], o[5]);
+            reproject_pixel(Q, (double)(4 * q + 2), yd, (double)dv.z, o[6], o[7], o[8]);
+            reproject_pixel(Q, (double)(4 * q + 3), yd, (double)dv.w, o[9], o[10], o[11]);
+            float4 *const op = reinterpret_cast<float4 *>(prow) + 3 * q;
+            op[0] = make_float4(o[0], o[1], o[2], o[3]);
+            op[1] = make_float4(o[4], o[5], o[6], o[7]);
+            op[2] = make_float4(o[8], o[9], o[10], o[11]);
+        }
+        return;
+    }
+    for (int x = t; x < W; x += nt) {
+        float ox, oy, oz;
+        reproject_pixel(Q, (double)x, yd, (double)drow[x], ox, oy, oz);
+        prow[3 * x] = ox; prow[3 * x + 1] = oy; prow[3 * x + 2] = oz;
     }
 }
 

@@ -1437,10 +1437,12 @@ int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const doubl
     hipStream_t s = (hipStream_t)stream;
     Mat4 q;
     for (int k = 0; k < 16; ++k) q.m[k] = Q[k];
-    const long long npix = (long long)h * w;
-    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 16);
+    if (h > 65535) return fail(SSAMD_ELIMIT, "more than 65535 rows");
+    if ((w & 3) == 0 && (((uintptr_t)d_disparity & 7) || ((uintptr_t)d_points & 15)))
+        return fail(SSAMD_EINVAL, "disparity / point buffers must be 8- / 16-byte aligned");
+    const int per_row = (w & 3) == 0 ? w / 4 : w;                 // threads a row needs
     Timed t(*c, s, SSAMD_K_REPROJECT);
-    hipLaunchKernelGGL(reproject_kernel, dim3(blocks), dim3(256), 0, s, d_disparity, d_points, h, w, q);
+    hipLaunchKernelGGL(reproject_kernel, dim3((per_row + 255) / 256, h), dim3(256), 0, s, d_disparity, d_points, h, w, q);
     HIP_TRY(hipGetLastError());
     return SSAMD_OK;
 }

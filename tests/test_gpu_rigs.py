@@ -105,14 +105,17 @@ def test_remap_kernel_odd_sizes_borders_and_last_pixels(shape, env):
         assert np.array_equal(out.cpu().numpy(), want), (shape, interp)
 
 
-def test_reproject_kernel_vs_oracle_and_host_path(env):
+@pytest.mark.parametrize("wh", [(64, 36), (37, 21), (1, 3), (260, 2)])
+def test_reproject_kernel_vs_oracle_and_host_path(wh, env):
+    """widths that are and are not a multiple of the four pixels a thread owns"""
     ss, torch, rig = env
     from oracle import rig_oracle
-    rig.computeRectificationMaps(destDims=(64, 36))
+    w, h = wh
+    rig.computeRectificationMaps(destDims=(w, h))
     rng = np.random.default_rng(5)
-    d = rng.integers(1, 60, (36, 64)).astype(np.int16)
+    d = rng.integers(1, 60, (h, w)).astype(np.int16)
     pts = rig.get3DPoints(torch.from_numpy(d).cuda())
-    assert pts.is_cuda and pts.dtype == torch.float32 and tuple(pts.shape) == (36, 64, 3)
+    assert pts.is_cuda and pts.dtype == torch.float32 and tuple(pts.shape) == (h, w, 3)
     host = rig.get3DPoints(d)
     ref = rig_oracle.reproject(d, rig.getQ())
     g = pts.cpu().numpy()
