@@ -1225,7 +1225,8 @@ int ssamd_device_count(void)
 
 const char *ssamd_kernel_name(int slot)
 {
-    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel", "asw_aggregate_kernel", "asw finalize (wta_decode / lr_check_fill)",
+    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel + asw_tad_volume_kernel", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
+                                               "asw finalize (wta_decode / lr_check_fill)",
                                                "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
                                                "asw_alt_fill_kernel"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";

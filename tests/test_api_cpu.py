@@ -113,7 +113,7 @@ def test_c_abi_exports_every_declared_symbol(ss):
     for sym in declared:
         assert hasattr(lib, sym), sym
     assert lib.ssamd_abi_version() == 1
-    assert lib.ssamd_kernel_name(1).decode().startswith("asw_aggregate")
+    assert "asw_aggregate" in lib.ssamd_kernel_name(1).decode()
 
 
 def test_geometry_query_is_sane(ss):
