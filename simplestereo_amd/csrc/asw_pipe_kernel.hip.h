@@ -349,7 +349,9 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
         AswRow ew[RX];
 
         for (int c = 0; c < NC; ++c) {
+#ifndef SSAMD_ABLATE_BARRIER          // (ablation build: how much of the time is waiting at this barrier; results are wrong without it)
             __syncthreads();       // buffers of chunk (i, c) complete; every wave is done with chunk (i, c) - 1
+#endif
             const int jc = c * JC, jend = chunk_end(c);
             const int rb = cb * g.JCmax;
             // waves 0-3 (one per SIMD) build first, their two SIMD-mates aggregate first and build afterwards
