@@ -54,6 +54,8 @@ __device__ __forceinline__ void asw_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+typedef float asw_v2f __attribute__((ext_vector_type(2)));
+
 // LDS instructions of one wave execute in issue order, so a wave's ds_read sees its own earlier ds_write without
 // waiting for it; only the compiler must keep the order.
 __device__ __forceinline__ void asw_wave_order()
@@ -70,6 +72,9 @@ __device__ __forceinline__ void asw_wave_order()
 #endif
 #ifndef SSAMD_WAVE8_OCC
 #define SSAMD_WAVE8_OCC 3
+#endif
+#ifndef SSAMD_WAVE_PKMUL         // 1: the tap products as v_pk_mul_f32 pairs (measured: 1.5-4 % slower)
+#define SSAMD_WAVE_PKMUL 0
 #endif
 // KL, KR: build rounds (64 centres each) of the left and of the right part when the host knows them at compile time
 // (the build is then straight-line code with immediate offsets); 0: counted at run time.
@@ -284,13 +289,30 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
                     wr[NWR - 4] = r2.x; wr[NWR - 3] = r2.y; wr[NWR - 2] = r2.z; wr[NWR - 1] = r2.w; \
                 }                                                                                   \
             }                                                                                       \
-            _Pragma("unroll") for (int xi = 0; xi < RX; ++xi) {                                     \
-                if (xi == RX - 1) asw_row_unpack(ew[((JJ) + RX - 1) % RX], epk);                    \
-                const AswRow &row_ = ew[((JJ) + xi) % RX];                                          \
-                _Pragma("unroll") for (int di = 0; di < ASW_RD; ++di) {                             \
-                    const float w_ = wl[xi] * wr[xi - di + ASW_RD - 1];                             \
-                    accN[xi][di] = fmaf(w_, row_.e[di], accN[xi][di]);                              \
-                    accS[xi][di] = fmaf(w_, row_.c[di], accS[xi][di]);                              \
+            _Pragma("unroll") for (int xi = 0; xi < RX; xi += 2) {                                  \
+                /* the products of two columns; (xi, di) and (xi + 1, di + 1) share the right weight: with SSAMD_WAVE_PKMUL */ \
+                /* one v_pk_mul_f32 with a broadcast operand each (same IEEE products, 5 instead of 8 instructions) */ \
+                float w_[2][ASW_RD];                                                                \
+                _Pragma("unroll") for (int di = 0; di + 1 < ASW_RD; ++di) {                         \
+                    const float s_ = wr[xi - di + ASW_RD - 1];                                      \
+                    if constexpr (SSAMD_WAVE_PKMUL) {                                               \
+                        const asw_v2f a_ = {wl[xi], wl[xi + 1]};                                    \
+                        const asw_v2f b_ = {s_, s_};                                                \
+                        const asw_v2f p_ = a_ * b_;                                                 \
+                        w_[0][di] = p_.x; w_[1][di + 1] = p_.y;                                     \
+                    } else {                                                                        \
+                        w_[0][di] = wl[xi] * s_; w_[1][di + 1] = wl[xi + 1] * s_;                   \
+                    }                                                                               \
+                }                                                                                   \
+                w_[0][ASW_RD - 1] = wl[xi] * wr[xi];                                                \
+                w_[1][0] = wl[xi + 1] * wr[xi + ASW_RD];                                            \
+                _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                     \
+                    if (xi + u == RX - 1) asw_row_unpack(ew[((JJ) + RX - 1) % RX], epk);            \
+                    const AswRow &row_ = ew[((JJ) + xi + u) % RX];                                  \
+                    _Pragma("unroll") for (int di = 0; di < ASW_RD; ++di) {                         \
+                        accN[xi + u][di] = fmaf(w_[u][di], row_.e[di], accN[xi + u][di]);           \
+                        accS[xi + u][di] = fmaf(w_[u][di], row_.c[di], accS[xi + u][di]);           \
+                    }                                                                               \
                 }                                                                                   \
             }                                                                                       \
         }                                                                                           \
