@@ -12,9 +12,33 @@ __constant__ float c_lin100[256];
 
 // CIE f(t) with the reference's precision mix: float powf above the knee, double
 // linear segment below (colorconversion.hpp:55-65).
+// powf(t, (float)(1 / 3.0)) for t in (0.008856, ~1.1] as the correctly rounded float (up to double-rounding ties) of the
+// real power: the device library's powf spends ~150 instructions per call on a general (x, y) -- 80 % of this kernel --
+// while a cube root needs a handful.  z = t^(-1/3) by two division-free Newton steps in fp64 from a v_log / v_exp seed
+// (1e-6 -> 1e-12 -> fp64 rounding), c = t z^2 = t^(1/3), and the exponent's distance from 1/3, dy = (float)(1/3.0) - 1/3 =
+// 9.93e-9, enters as t^dy = 1 + dy ln t (next term 1e-16).  The reference's glibc powf is within 0.82 ulp of the same real.
+#ifndef SSAMD_LAB_LIBM_POWF
+__device__ __forceinline__ float lab_pow_third(float tf)
+{
+    const double t = (double)tf;
+    const float l2 = __builtin_amdgcn_logf(tf);                          // v_log_f32: log2(t)
+    double z = (double)__builtin_amdgcn_exp2f(l2 * -0.33333334f);      // t^(-1/3), ~1e-6
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double z3 = z * z * z;
+        z = z * fma(-t, z3, 4.0) * (1.0 / 3.0);                          // z <- z (4 - t z^3) / 3
+    }
+    const double c = t * z * z;
+    const double dy = (double)(float)(1 / 3.0) - 1.0 / 3.0;
+    return (float)fma(c * dy, (double)(l2 * 0.6931471805599453f), c);
+}
+#else
+__device__ __forceinline__ float lab_pow_third(float tf) { return powf(tf, (float)(1 / 3.0)); }
+#endif
+
 __device__ __forceinline__ double lab_f(double t)
 {
-    if (t > 0.008856) return (double)powf((float)t, (float)(1 / 3.0));
+    if (t > 0.008856) return (double)lab_pow_third((float)t);
     return (7.787 * t) + (16.0 / 116.0);
 }
 

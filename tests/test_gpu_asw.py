@@ -90,7 +90,10 @@ def test_lab_conversion_vs_oracle(ss, tsukuba):
     cube = np.stack(np.meshgrid(ramp[::5], ramp[::5], ramp[::5], indexing="ij"), -1).reshape(1, -1, 3).copy()
     lab2 = np.empty(cube.shape, np.float32)
     _native.check(_native.lib().ssamd_bgr2lab(cube.ctypes.data, 1, cube.shape[1], lab2.ctypes.data, -1))
-    assert np.abs(lab2 - oracle.bgr2lab(cube)).max() <= 2e-3
+    ref2 = oracle.bgr2lab(cube)
+    assert np.abs(lab2 - ref2).max() <= 1e-4
+    # the cube root is evaluated in fp64 (lab_pow_third): nearly every value is the reference's double rounded to float
+    assert float(np.mean(lab2 == ref2.astype(np.float32))) >= 0.995
 
 
 def test_asw_device_tensor_path_and_strips_bit_exact(ss, golden_inputs):
