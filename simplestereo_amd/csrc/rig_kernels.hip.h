@@ -96,9 +96,17 @@ __device__ __forceinline__ void reproject_pixel(const Mat4 &Q, double x, double 
     const double Y = Q.m[4] * x + Q.m[5] * y + Q.m[6] * d + Q.m[7];
     const double Z = Q.m[8] * x + Q.m[9] * y + Q.m[10] * d + Q.m[11];
     const double Wc = Q.m[12] * x + Q.m[13] * y + Q.m[14] * d + Q.m[15];
-    ox = (float)(X / Wc);
-    oy = (float)(Y / Wc);
-    oz = (float)(Z / Wc);
+    // three quotients by the same (finite) divisor: one reciprocal, then q = X r corrected by one fma pair on the exact
+    // remainder -- the correctly rounded quotient in all but double-rounding corner cases, which the float cast below
+    // hides; W = 0 keeps q = +-inf / nan, exactly what the plain divisions give
+    const double r = 1.0 / Wc;
+    auto quot = [&](double n) {
+        const double q = n * r;
+        return (float)(__builtin_isfinite(q) ? fma(fma(-q, Wc, n), r, q) : q);
+    };
+    ox = quot(X);
+    oy = quot(Y);
+    oz = quot(Z);
 }
 
 __global__ __launch_bounds__(256) void reproject_kernel(const int16_t *__restrict__ disp, float *__restrict__ pts,
@@ -109,18 +117,35 @@ __global__ __launch_bounds__(256) void reproject_kernel(const int16_t *__restric
     const int16_t *const drow = disp + (size_t)y * W;
     float *const prow = pts + (size_t)y * W * 3;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    __shared__ float4 xchg[4][192];
+    const int lane = threadIdx.x & 63;
     if ((W & 3) == 0) {
-        for (int q = t; 4 * q < W; q += nt) {
-            const short4 dv = reinterpret_cast<const short4 *>(drow)[q];
-            float o[12];
-            reproject_pixel(Q, (double)(4 * q), yd, (double)dv.x, o[0], o[1], o[2]);
-            reproject_pixel(Q, (double)(4 * q + 1), yd, (double)dv.y, o[3], o[4], o[5]);
-            reproject_pixel(Q, (double)(4 * q + 2), yd, (double)dv.z, o[6], o[7], o[8]);
-            reproject_pixel(Q, (double)(4 * q + 3), yd, (double)dv.w, o[9], o[10], o[11]);
-            float4 *const op = reinterpret_cast<float4 *>(prow) + 3 * q;
-            op[0] = make_float4(o[0], o[1], o[2], o[3]);
-            op[1] = make_float4(o[4], o[5], o[6], o[7]);
-            op[2] = make_float4(o[8], o[9], o[10], o[11]);
+        // whole waves iterate (q0 = the wave's first quad): lanes past the row's last quad compute nothing but help write
+        for (int q0 = t - lane; 4 * q0 < W; q0 += nt) {
+            const int q = q0 + lane;
+            float4 *const mine = xchg[threadIdx.x >> 6] + 3 * lane;
+            if (4 * q < W) {
+                const short4 dv = reinterpret_cast<const short4 *>(drow)[q];
+                float o[12];
+                reproject_pixel(Q, (double)(4 * q), yd, (double)dv.x, o[0], o[1], o[2]);
+                reproject_pixel(Q, (double)(4 * q + 1), yd, (double)dv.y, o[3], o[4], o[5]);
+                reproject_pixel(Q, (double)(4 * q + 2), yd, (double)dv.z, o[6], o[7], o[8]);
+                reproject_pixel(Q, (double)(4 * q + 3), yd, (double)dv.w, o[9], o[10], o[11]);
+                mine[0] = make_float4(o[0], o[1], o[2], o[3]);
+                mine[1] = make_float4(o[4], o[5], o[6], o[7]);
+                mine[2] = make_float4(o[8], o[9], o[10], o[11]);
+            }
+            // the wave's up to 64 x 48 bytes go out as three fully contiguous 1 KiB stores: the 16-byte chunks are
+            // transposed through LDS (a wave's LDS accesses execute in order: no barrier), lane l writes chunks l, l + 64, l + 128
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int nchunk = 3 * min(64, W / 4 - q0);
+            float4 *const op = reinterpret_cast<float4 *>(prow) + 3 * q0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (lane + 64 * k < nchunk) op[lane + 64 * k] = xchg[threadIdx.x >> 6][lane + 64 * k];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
