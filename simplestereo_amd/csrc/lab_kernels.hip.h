@@ -14,19 +14,20 @@ __constant__ float c_lin100[256];
 // linear segment below (colorconversion.hpp:55-65).
 // powf(t, (float)(1 / 3.0)) for t in (0.008856, ~1.1] as the correctly rounded float (up to double-rounding ties) of the
 // real power: the device library's powf spends ~150 instructions per call on a general (x, y) -- 80 % of this kernel --
-// while a cube root needs a handful.  z = t^(-1/3) by two division-free Newton steps in fp64 from a v_log / v_exp seed
-// (1e-6 -> 1e-12 -> fp64 rounding), c = t z^2 = t^(1/3), and the exponent's distance from 1/3, dy = (float)(1/3.0) - 1/3 =
+// while a cube root needs a handful.  z = t^(-1/3) by division-free Newton steps from a v_log / v_exp seed, one in fp32 and
+// one in fp64 (1e-6 -> 1e-7 -> 1e-14), c = t z^2 = t^(1/3), and the exponent's distance from 1/3, dy = (float)(1/3.0) - 1/3 =
 // 9.93e-9, enters as t^dy = 1 + dy ln t (next term 1e-16).  The reference's glibc powf is within 0.82 ulp of the same real.
 #ifndef SSAMD_LAB_LIBM_POWF
 __device__ __forceinline__ float lab_pow_third(float tf)
 {
     const double t = (double)tf;
     const float l2 = __builtin_amdgcn_logf(tf);                          // v_log_f32: log2(t)
-    double z = (double)__builtin_amdgcn_exp2f(l2 * -0.33333334f);      // t^(-1/3), ~1e-6
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    float zf = __builtin_amdgcn_exp2f(l2 * -0.33333334f);              // t^(-1/3), ~1e-6
+    zf = zf * fmaf(-tf, zf * zf * zf, 4.0f) * 0.33333334f;              // one step in fp32: ~1e-7
+    double z = (double)zf;
+    {
         const double z3 = z * z * z;
-        z = z * fma(-t, z3, 4.0) * (1.0 / 3.0);                          // z <- z (4 - t z^3) / 3
+        z = z * fma(-t, z3, 4.0) * (1.0 / 3.0);                          // z <- z (4 - t z^3) / 3: ~1e-14
     }
     const double c = t * z * z;
     const double dy = (double)(float)(1 / 3.0) - 1.0 / 3.0;
@@ -63,8 +64,15 @@ __global__ __launch_bounds__(256) void bgr2lab_records_kernel(const uint8_t *__r
 {
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     for (; p < npix; p += stride) {
-        const uint32_t B = bgr[3 * p], G = bgr[3 * p + 1], R = bgr[3 * p + 2];
+        uint32_t B, G, R;
+        if (p + 1 < npix) {                 // one unaligned 4-byte read instead of three byte reads (the 4th byte is the next pixel's)
+            const uint32_t v = *reinterpret_cast<const u32_unaligned *>(bgr + 3 * p);
+            B = v & 0xff; G = (v >> 8) & 0xff; R = (v >> 16) & 0xff;
+        } else {
+            B = bgr[3 * p]; G = bgr[3 * p + 1]; R = bgr[3 * p + 2];
+        }
         PixRec o;
         bgr_to_lab(B, G, R, o.L, o.a, o.b);
         o.bgrx = B | (G << 8) | (R << 16);
