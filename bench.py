@@ -437,6 +437,14 @@ def main():
                                            "note": "opt-in StereoASW(alternate=True); not the reference's output, never `value`"}
         if world == 1 and not args.no_others:
             line["others"] = others(dev, args.seed)
+            # the pointwise kernels either side of the matchers (Lab records, rectification remap, 3-D reprojection)
+            # against the HBM roofline: tools/bench_pointwise.py
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_pointwise
+                line["pointwise_kernels"] = bench_pointwise.measure()
+            except Exception as e:      # noqa: BLE001
+                line["pointwise_kernels"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1])
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
@@ -451,6 +459,27 @@ def main():
                 line["bad1_vs_cpu_ref"] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
                                            "pixels": int(diff.size), "what": "GPU vs CPU %s map of the cpu_baseline crop (the 1920- and "
                                            "4096-wide launch geometries are pinned by tests/test_gpu_wide_golden.py)" % cb["kind"]}
+                # how many of the differing pixels are numerical ties: the raw GPU cost at the reference's disparity is
+                # within the stated raw-cost tolerance (1e-4 relative) of the GPU's own minimum -- either choice is a
+                # minimum within the arithmetic (a stand-alone 512-column crop of a D 0..192 frame has wide bands where most
+                # candidates fall outside the image and the truncated costs saturate)
+                try:
+                    cl = np.ascontiguousarray(L[r0s:r0s + rws, c0s:c0s + cls])
+                    cr = np.ascontiguousarray(R[r0s:r0s + rws, c0s:c0s + cls])
+                    costs = np.empty((rws, cls, nD), np.float32)
+                    _native.check(lib.ssamd_asw_costs(cl.ctypes.data, cr.ctypes.data, rws, cls, win, maxD, minD, float(GAMMA_C), float(GAMMA_P),
+                                                      costs.ctypes.data, -1))
+                    yy, xx = np.mgrid[0:rws, 0:cls]
+                    gi = np.clip(gpu_map.astype(np.int64) - minD, 0, nD - 1)
+                    ri = np.clip(ref_map.astype(np.int64) - minD, 0, nD - 1)
+                    cg, cr_ = costs[yy, xx, gi], costs[yy, xx, ri]
+                    tie = np.abs(cr_ - cg) <= 1e-4 * np.maximum(1.0, np.abs(cg))
+                    line["bad1_vs_cpu_ref"]["percent_excluding_numerical_ties"] = 100.0 * float(np.mean((diff > 1) & ~tie))
+                    line["bad1_vs_cpu_ref"]["numerical_ties_among_bad1_percent"] = 100.0 * float(np.mean((diff > 1) & tie))
+                    tie6 = np.abs(cr_ - cg) <= 1e-6 * np.maximum(1.0, np.abs(cg))
+                    line["bad1_vs_cpu_ref"]["percent_excluding_ties_at_1e-6"] = 100.0 * float(np.mean((diff > 1) & ~tie6))
+                except Exception as e:      # noqa: BLE001
+                    line["bad1_vs_cpu_ref"]["percent_excluding_numerical_ties"] = repr(e)[:120]
             except Exception as e:      # noqa: BLE001
                 line["bad1_vs_cpu_ref"] = {"percent": None, "what": repr(e)[:160]}
             cb.pop("map_file", None)

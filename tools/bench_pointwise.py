@@ -16,50 +16,62 @@ import simplestereo_amd as ss
 from simplestereo_amd import _native
 
 HBM_PEAK = 8.0e12
-lib = _native.lib()
-res = {}
-for H, W in ((1080, 1920), (2160, 4096)):
-    rng = np.random.default_rng(0)
-    img = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
-    # a mild rotation + shift as the rectifying map (neighbouring outputs read neighbouring sources)
-    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
-    mapx = (xx * 0.999 + yy * 0.01 + 1.3).astype(np.float32)
-    mapy = (yy * 0.999 - xx * 0.004 + 0.7).astype(np.float32)
-    dmx, dmy = torch.from_numpy(mapx).cuda(), torch.from_numpy(mapy).cuda()
-    out = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-    disp = torch.from_numpy(rng.integers(1, 192, (H, W), dtype=np.int16)).cuda()
-    pts = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-    Q = np.array([[1, 0, 0, -W / 2], [0, 1, 0, -H / 2], [0, 0, 0, 1000.0], [0, 0, 1 / 120.0, 0]], np.float64)
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def remap():
-        _native.check(lib.ssamd_remap_bgr_device(img.data_ptr(), H, W, dmx.data_ptr(), dmy.data_ptr(), H, W, 1, out.data_ptr(), stream))
 
-    def reproject():
-        _native.check(lib.ssamd_reproject_device(disp.data_ptr(), H, W, Q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), pts.data_ptr(), stream))
-    m = ss.passive.StereoASW(winSize=5, maxDisparity=3)
+def measure(sizes=((1080, 1920), (2160, 4096))):
+    lib = _native.lib()
+    res = {}
+    was = os.environ.get("SSAMD_ASW_WAVE")
+    for H, W in sizes:
+        rng = np.random.default_rng(0)
+        img = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
+        # a mild rotation + shift as the rectifying map (neighbouring outputs read neighbouring sources)
+        yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        mapx = (xx * 0.999 + yy * 0.01 + 1.3).astype(np.float32)
+        mapy = (yy * 0.999 - xx * 0.004 + 0.7).astype(np.float32)
+        dmx, dmy = torch.from_numpy(mapx).cuda(), torch.from_numpy(mapy).cuda()
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        disp = torch.from_numpy(rng.integers(1, 192, (H, W), dtype=np.int16)).cuda()
+        pts = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        Q = np.array([[1, 0, 0, -W / 2], [0, 1, 0, -H / 2], [0, 0, 0, 1000.0], [0, 0, 1 / 120.0, 0]], np.float64)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    os.environ["SSAMD_ASW_WAVE"] = "0"        # round-1 kernel for this tiny range: the K_LAB slot then holds the two record launches only
+        def remap():
+            _native.check(lib.ssamd_remap_bgr_device(img.data_ptr(), H, W, dmx.data_ptr(), dmy.data_ptr(), H, W, 1, out.data_ptr(), stream))
 
-    def lab():
-        m.compute(img, img)
-    for name, fn, slot, bpp, launches_per_call in (("K5 remap_bgr_kernel", remap, _native.K_REMAP, 8 + 3 + 3, 1),
-                                                   ("K6 reproject_kernel", reproject, _native.K_REPROJECT, 2 + 12, 1),
-                                                   ("K0 bgr2lab_records_kernel", lab, _native.K_LAB, 3 + 16, 2)):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        lib.ssamd_profile_enable(1)
-        lib.ssamd_profile_reset()
-        for _ in range(20):
-            fn()
-        torch.cuda.synchronize()
-        ms, launches = _native.profile_read()
-        lib.ssamd_profile_enable(0)
-        per = ms[slot] / max(1, launches[slot])          # ms per launch
-        if name.startswith("K0"):
-            assert launches[slot] == 40, launches[slot]
-        gbs = bpp * H * W / (per * 1e-3) / 1e9
-        res["%s %dx%d" % (name, W, H)] = {"ms": round(per, 4), "algorithmic_bytes_per_pixel": bpp, "GB/s": round(gbs, 1),
-                                         "frac_of_8TB/s": round(gbs * 1e9 / HBM_PEAK, 3)}
-print(json.dumps(res))
+        def reproject():
+            _native.check(lib.ssamd_reproject_device(disp.data_ptr(), H, W, Q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), pts.data_ptr(), stream))
+        m = ss.passive.StereoASW(winSize=5, maxDisparity=3)
+
+        os.environ["SSAMD_ASW_WAVE"] = "0"        # round-1 kernel for this tiny range: the K_LAB slot then holds the two record launches only
+
+        def lab():
+            m.compute(img, img)
+        for name, fn, slot, bpp, launches_per_call in (("K5 remap_bgr_kernel", remap, _native.K_REMAP, 8 + 3 + 3, 1),
+                                                       ("K6 reproject_kernel", reproject, _native.K_REPROJECT, 2 + 12, 1),
+                                                       ("K0 bgr2lab_records_kernel", lab, _native.K_LAB, 3 + 16, 2)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            lib.ssamd_profile_enable(1)
+            lib.ssamd_profile_reset()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            ms, launches = _native.profile_read()
+            lib.ssamd_profile_enable(0)
+            per = ms[slot] / max(1, launches[slot])          # ms per launch
+            if name.startswith("K0"):
+                assert launches[slot] == 40, launches[slot]
+            gbs = bpp * H * W / (per * 1e-3) / 1e9
+            res["%s %dx%d" % (name, W, H)] = {"ms": round(per, 4), "algorithmic_bytes_per_pixel": bpp, "GB/s": round(gbs, 1),
+                                             "frac_of_8TB/s": round(gbs * 1e9 / HBM_PEAK, 3)}
+    if was is None:
+        os.environ.pop("SSAMD_ASW_WAVE", None)
+    else:
+        os.environ["SSAMD_ASW_WAVE"] = was
+    return res
+
+
+if __name__ == "__main__":
+    print(json.dumps(measure()))
