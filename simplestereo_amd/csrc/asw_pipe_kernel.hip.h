@@ -73,9 +73,7 @@ __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__res
     __syncthreads();
     const int ncols = min(TADV_COLS, evolW - uc0);
     uint32_t *const out = reinterpret_cast<uint32_t *>(evol + (((size_t)z * erows + blockIdx.y) * (size_t)evolW + uc0) * Se);
-    for (int k = threadIdx.x; k < ncols * P; k += blockDim.x) {
-        const int c = k / P, slot = k - c * P;
-        const uint32_t lp = sL[c];
+    auto dword = [&](int c, int slot, uint32_t lp) {             // the four disparities dlo + 4 slot + 0..3 of column c
         uint32_t v = 0;
         if (!(lp >> 31) && 4 * slot < Dc) {
             // R[u - d] for d = dlo + 4 slot + q  ->  staged index c + (Dc - 1) - 4 slot - q
@@ -86,7 +84,23 @@ __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__res
                 if (!(rv >> 31)) v |= min(__builtin_amdgcn_sad_u8(lp, rv, 0u), 40u) << (8 * q);
             }
         }
-        out[k] = v;
+        return v;
+    };
+    if ((P & 3) == 0) {
+        // rows of whole 16-byte blocks (the phase-shifted kernel's layout): a thread produces 16 disparities and one
+        // 16-byte store -- 1 KiB per wave and store instruction instead of 256 B
+        const int P4 = P >> 2;
+        uint4 *const out4 = reinterpret_cast<uint4 *>(out);
+        for (int k = threadIdx.x; k < ncols * P4; k += blockDim.x) {
+            const int c = k / P4, s4 = 4 * (k - c * P4);
+            const uint32_t lp = sL[c];
+            out4[k] = make_uint4(dword(c, s4, lp), dword(c, s4 + 1, lp), dword(c, s4 + 2, lp), dword(c, s4 + 3, lp));
+        }
+        return;
+    }
+    for (int k = threadIdx.x; k < ncols * P; k += blockDim.x) {
+        const int c = k / P, slot = k - c * P;
+        out[k] = dword(c, slot, sL[c]);
     }
 }
 
