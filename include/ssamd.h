@@ -128,13 +128,15 @@ int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int
 /* RectifiedStereoRig.rectifyImages (reference _rigs.py:543-567 = cv2.remap with constant
  * border): d_dst[y][x] = bilinear(d_src, d_mapx[y][x], d_mapy[y][x]).  d_src is uint8
  * [src_h][src_w][3]; maps are float32 [dst_h][dst_w] (cv2.initUndistortRectifyMap layout,
- * built once per rig on the host); interpolation 0 = nearest, 1 = linear. */
+ * built once per rig on the host); interpolation 0 = nearest, 1 = linear.  The maps must be 16-byte and d_dst 4-byte
+ * aligned (any device allocation is): a thread owns four consecutive output pixels. */
 int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
                            int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream);
 
 /* RectifiedStereoRig.get3DPoints (reference _rigs.py:569-628 = cv2.reprojectImageTo3D):
  * d_points float32 [h][w][3] from int16 disparities and the 4x4 matrix Q (16 doubles, row
- * major, HOST memory). */
+ * major, HOST memory).  h <= 65535; when w is a multiple of 4 (four pixels per thread) d_disparity must be 8-byte and
+ * d_points 16-byte aligned (any device allocation is). */
 int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const double *Q, float *d_points, void *stream);
 
 /* ---- verification / measurement helpers ------------------------------------ */
