@@ -123,6 +123,20 @@ int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int
                                double gammaC, double gammaP, int consistent,
                                int16_t *d_disparity, void *stream);
 
+/* The same mode on a row range of a (sub-)image (row strips of a frame cut across GPUs or processes): rows whose index
+ * in the WHOLE image is even are matched exactly, the odd ones filled from their two exact neighbours.  row_parity =
+ * parity (0 / 1) of the sub-image's row 0 in the whole image.  A range that starts or ends with an odd row needs the
+ * exact row just outside it: the sub-image must carry winSize/2 + 1 halo rows (fewer only at the borders of the whole
+ * image).  d_disparity is int16 [out_rows][width]. */
+int ssamd_asw_alternate_rows_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                                    int row_parity, int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP,
+                                    int consistent, int16_t *d_disparity, void *stream);
+
+/* ssamd_asw_multi for the alternate-rows mode: one row strip per listed GPU (halo of winSize/2 + 1 rows). */
+int ssamd_asw_alternate_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                              int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                              const int *devices, int n_devices);
+
 /* ---- the steps either side of the matchers, on device --------- */
 
 /* RectifiedStereoRig.rectifyImages (reference _rigs.py:543-567 = cv2.remap with constant

@@ -67,6 +67,10 @@ def lib():
     L.ssamd_asw_alternate.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
     L.ssamd_asw_alternate_device.restype = I
     L.ssamd_asw_alternate_device.argtypes = [P, P, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_asw_alternate_rows_device.restype = I
+    L.ssamd_asw_alternate_rows_device.argtypes = [P, P, I, I, I, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_asw_alternate_multi.restype = I
+    L.ssamd_asw_alternate_multi.argtypes = [P, P, I, I, I, I, I, D, D, I, P, ctypes.POINTER(I), I]
     L.ssamd_asw_costs.restype = I
     L.ssamd_asw_costs.argtypes = [P, P, I, I, I, I, I, D, D, P, I]
     L.ssamd_asw_argmins.restype = I

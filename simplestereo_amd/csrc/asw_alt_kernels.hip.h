@@ -24,12 +24,13 @@ static constexpr int ASW_ALT_JC = 8;        // candidates per job
 struct AswAltArgs {
     const PixRec *recL, *recR;   // [H][W] pixel records
     const float *prox;           // [win*win]
-    int16_t *disp;               // [H][W]: even rows hold exact disparities, odd rows are written here
-    u64 *key;                    // [H][W] WTA keys; odd rows arrive as KEY_NONE
+    int16_t *disp;               // [rows][W], row 0 = image row row0: rows 0, 2, .. hold exact disparities, rows 1, 3, .. are written here
+    u64 *key;                    // [rows][W] WTA keys; the odd rows arrive as KEY_NONE
     u64 *queue;                  // [cap] jobs: pixel index | first candidate << 32 | candidate count << 48
     unsigned int *ctr;           // [0] jobs appended
     unsigned int cap;
     int H, W, win, pad, minD, maxD;
+    int row0, rows;              // output rows [row0, row0 + rows) of the (sub-)image; row0 is an exactly matched row
     float kC;                    // -log2(e)/gammaC
 };
 
@@ -104,22 +105,23 @@ __device__ __forceinline__ u64 asw_alt_eval(const AswAltArgs &A, int y, int x, i
 __global__ __launch_bounds__(256) void asw_alt_scan_kernel(const AswAltArgs A)
 {
     const int lane = threadIdx.x & 63;
-    const int y = 2 * blockIdx.y + 1;
-    const int W = A.W, H = A.H;
-    if (y >= H) return;
+    const int yr = 2 * blockIdx.y + 1, y = A.row0 + yr;             // row of the output range / of the image
+    const int W = A.W;
+    if (yr >= A.rows) return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int16_t *const up = A.disp + (size_t)(y - 1) * W;
-    const int16_t *const down = (y + 1 < H) ? A.disp + (size_t)(y + 1) * W : up;
+    int16_t *const drow = A.disp + (size_t)yr * W;
+    const int16_t *const up = drow - W;
+    const int16_t *const down = (yr + 1 < A.rows) ? drow + W : up;    // (the range ends with an exact row or with the image)
     int lo = 0, cnt = 0;
     if (x < W) {
         const int dmaxv = min(A.maxD, x);
         if (A.minD > dmaxv) {
-            A.disp[(size_t)y * W + x] = (int16_t)x;                  // empty candidate loop: dBest = 0 -> x
+            drow[x] = (int16_t)x;                                    // empty candidate loop: dBest = 0 -> x
         } else {
             const int a = up[x], b = down[x];
             lo = min(max(min(a, b), A.minD), dmaxv);
             const int hi = min(max(max(a, b), A.minD), dmaxv);
-            if (lo == hi) A.disp[(size_t)y * W + x] = (int16_t)lo;
+            if (lo == hi) drow[x] = (int16_t)lo;
             else cnt = hi - lo + 1;
         }
     }
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void asw_alt_scan_kernel(const AswAltArgs A)
     if (lane == 0) base = atomicAdd(&A.ctr[0], (unsigned int)total);
     base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
     if ((u64)base + (u64)total <= (u64)A.cap) {
-        const u64 pix = (u64)((size_t)y * W + x);
+        const u64 pix = (u64)((size_t)yr * W + x);                    // index into disp / key
         for (int k = 0; k < njobs; ++k)
             A.queue[base + incl - njobs + k] =
                 pix | ((u64)(uint32_t)(lo + ASW_ALT_JC * k) << 32) | ((u64)(uint32_t)min(ASW_ALT_JC, cnt - ASW_ALT_JC * k) << 48);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void asw_alt_scan_kernel(const AswAltArgs A)
         u64 best = KEY_NONE;
         for (int d0 = los; d0 < los + cs; d0 += ASW_ALT_JC)
             best = min(best, asw_alt_eval(A, y, xs, d0, min(ASW_ALT_JC, los + cs - d0), lane));
-        if (lane == 0) A.disp[(size_t)y * W + xs] = (int16_t)(uint32_t)best;
+        if (lane == 0) drow[xs] = (int16_t)(uint32_t)best;
     }
 }
 
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(256) void asw_alt_jobs_kernel(const AswAltArgs A)
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(job >> 32));
         const int cnt = (int)(hi >> 16), d0 = (int)(hi & 0xffffu);
         if (cnt > 0) {
-            const int y = (int)(pix / (uint32_t)A.W), x = (int)(pix - (uint32_t)y * (uint32_t)A.W);
-            const u64 best = asw_alt_eval(A, y, x, d0, cnt, lane);
+            const int yr = (int)(pix / (uint32_t)A.W), x = (int)(pix - (uint32_t)yr * (uint32_t)A.W);
+            const u64 best = asw_alt_eval(A, A.row0 + yr, x, d0, cnt, lane);
             if (lane == 0) atomicMin(&A.key[pix], best);
         }
     }
@@ -183,11 +185,11 @@ __global__ __launch_bounds__(256) void asw_alt_jobs_kernel(const AswAltArgs A)
 // Step 3: odd-row pixels that went through the queue take the disparity of their best key.
 __global__ __launch_bounds__(256) void asw_alt_decode_kernel(const AswAltArgs A)
 {
-    const int y = 2 * blockIdx.y + 1;
+    const int yr = 2 * blockIdx.y + 1;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= A.H || x >= A.W) return;
-    const u64 k = A.key[(size_t)y * A.W + x];
-    if (k != KEY_NONE) A.disp[(size_t)y * A.W + x] = (int16_t)(uint32_t)k;
+    if (yr >= A.rows || x >= A.W) return;
+    const u64 k = A.key[(size_t)yr * A.W + x];
+    if (k != KEY_NONE) A.disp[(size_t)yr * A.W + x] = (int16_t)(uint32_t)k;
 }
 
 }  // namespace ssamd

@@ -130,7 +130,7 @@ struct Ctx {
     int dev = -1;
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
-    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol;
+    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol, altdisp;
     TableCache proxTabs{8}, gswTabs{4};
     std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
@@ -701,8 +701,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
-    if (alternate && (d_costs || row0 != 0 || rows != H))
-        return fail(SSAMD_EINVAL, "the alternate-rows mode takes the whole image and no cost dump");
+    // alternate-rows mode: row0 is matched exactly, then every second row; the range must end with an exact row or with
+    // the image (asw_alternate_rows arranges that for strips)
+    if (alternate && d_costs) return fail(SSAMD_EINVAL, "the alternate-rows mode has no cost dump");
     if (rows == 0) return SSAMD_OK;
     ScratchOrder order(c, s);
     const int p = win / 2, nD = maxD - minD + 1;
@@ -890,7 +891,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         HIP_TRY(hipMemsetAsync(f.ctr, 0, 16, s));
         f.recL = (const PixRec *)c.recL.ptr; f.recR = (const PixRec *)c.recR.ptr; f.prox = a.prox;
         f.disp = d_disp; f.key = (u64 *)c.keyL.ptr;
-        f.H = H; f.W = W; f.win = win; f.pad = p; f.minD = minD; f.maxD = maxD;
+        f.H = H; f.W = W; f.win = win; f.pad = p; f.minD = minD; f.maxD = maxD; f.row0 = row0; f.rows = rows;
         f.kC = (float)(-1.4426950408889634 / gammaC);
         const dim3 pix_grid((W + 255) / 256, rows / 2);
         Timed t(c, s, SSAMD_K_ASW_ALT);
@@ -902,6 +903,30 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     return SSAMD_OK;
 }
 
+
+// The alternate-rows mode on a row range of a (sub-)image.  row_parity = parity of the sub-image's row 0 in the whole
+// image: rows whose index in the whole image is even are matched exactly, the odd ones are filled from their two exact
+// neighbours -- so a range that starts or ends with an odd row also needs the exact row just outside it (the caller's
+// halo is winSize/2 + 1 rows then).  Those rows are computed into a scratch map and the requested rows copied out.
+int asw_alternate_rows(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int row_parity, int win,
+                       int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp, hipStream_t s)
+{
+    int rc = check_common(H, W, win, minD, maxD, row0, rows);
+    if (rc) return rc;
+    if (rows == 0) return SSAMD_OK;
+    const bool top_odd = ((row0 + row_parity) & 1) != 0, bottom_odd = ((row0 + rows - 1 + row_parity) & 1) != 0;
+    if (top_odd && row0 == 0)
+        return fail(SSAMD_EINVAL, "alternate rows: the first output row is an odd row of the image, the sub-image must start at least one row above it");
+    const int e0 = top_odd ? row0 - 1 : row0, e1 = bottom_odd ? std::min(H, row0 + rows + 1) : row0 + rows;
+    if (e0 == row0 && e1 == row0 + rows)
+        return asw_device_impl(c, dL, dR, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent, d_disp, nullptr, s, true);
+    ScratchOrder order(c, s);
+    if ((rc = c.altdisp.reserve((size_t)(e1 - e0) * W * 2))) return rc;
+    rc = asw_device_impl(c, dL, dR, H, W, e0, e1 - e0, win, maxD, minD, gammaC, gammaP, consistent, (int16_t *)c.altdisp.ptr, nullptr, s, true);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_disp, (const int16_t *)c.altdisp.ptr + (size_t)(row0 - e0) * W, (size_t)rows * W * 2, hipMemcpyDeviceToDevice, s));
+    return SSAMD_OK;
+}
 
 // ------------------------------------------------------------ GSW
 bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
@@ -1109,7 +1134,8 @@ int asw_host_rows(const HostJob &j, int device)
     int rc = get_ctx(device, c);
     if (rc) return rc;
     if ((rc = check_common(j.H, j.W, j.win, j.minD, j.maxD, j.o0, j.o1 - j.o0))) return rc;
-    const int p = j.win / 2, in0 = std::max(0, j.o0 - p), in1 = std::min(j.H, j.o1 + p), rows = j.o1 - j.o0;
+    const int p = j.win / 2 + (j.alternate ? 1 : 0);        // alternate rows: + the exact row beyond an odd first / last row
+    const int in0 = std::max(0, j.o0 - p), in1 = std::min(j.H, j.o1 + p), rows = j.o1 - j.o0;
     const size_t nb = (size_t)(in1 - in0) * j.W * 3, nout = (size_t)rows * j.W;
     if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
     const size_t ncost = j.costs ? nout * (size_t)std::max(1, j.maxD - j.minD + 1) : 0;
@@ -1119,10 +1145,14 @@ int asw_host_rows(const HostJob &j, int device)
     HIP_TRY(hipMemcpyAsync(c->imgL.ptr, j.img1 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->imgR.ptr, j.img2 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
     if (j.costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
-    rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
-                         j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr,
-                         j.costs ? (float *)c->costs.ptr : nullptr, s, j.alternate,
-                         j.raw_right ? (int16_t *)c->lab.ptr : nullptr);
+    if (j.alternate)
+        rc = asw_alternate_rows(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows, in0 & 1,
+                                j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr, s);
+    else
+        rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
+                             j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr,
+                             j.costs ? (float *)c->costs.ptr : nullptr, s, false,
+                             j.raw_right ? (int16_t *)c->lab.ptr : nullptr);
     if (rc) return rc;
     if (j.raw_right)
         HIP_TRY(hipMemcpyAsync(j.raw_right + (size_t)j.o0 * j.W, c->lab.ptr, nout * 2, hipMemcpyDeviceToHost, s));
@@ -1332,6 +1362,28 @@ int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC,
                            gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream, true);
+}
+
+int ssamd_asw_alternate_rows_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                                    int row_parity, int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP,
+                                    int consistent, int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (row_parity != 0 && row_parity != 1) return fail(SSAMD_EINVAL, "row_parity must be 0 or 1");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    return asw_alternate_rows(*c, d_img1, d_img2, height, width, out_row0, out_rows, row_parity, winSize, maxDisparity, minDisparity,
+                              gammaC, gammaP, consistent, d_disparity, (hipStream_t)stream);
+}
+
+int ssamd_asw_alternate_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                              int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                              const int *devices, int n_devices)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return run_strips(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                              disparity, nullptr, true), devices, n_devices, asw_host_rows);
 }
 
 int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,

@@ -186,12 +186,8 @@ class StereoASW():
         gc, gp = _c_double(self.gammaC), _c_double(self.gammaP)
         return win, maxd, mind, gc, gp, 1 if self.consistent else 0
 
-    def _alternate(self, cons, whole_image=True):
-        if not getattr(self, "alternate", False):
-            return False
-        if not whole_image:
-            raise ValueError("alternate=True needs the whole image (no row strips)")
-        return True
+    def _alternate(self, cons):
+        return bool(getattr(self, "alternate", False))
 
     def compute(self, img1, img2, devices=None):
         """
@@ -218,10 +214,9 @@ class StereoASW():
         out = np.empty((H, W), np.int16)
         try:
             if devices is not None:
-                self._alternate(cons, whole_image=False)      # alternate=True raises: that mode takes whole images
                 arr, n = _device_list(devices)
-                _native.check(lib.ssamd_asw_multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
-                                                  out.ctypes.data, arr, n))
+                multi = lib.ssamd_asw_alternate_multi if self._alternate(cons) else lib.ssamd_asw_multi
+                _native.check(multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons, out.ctypes.data, arr, n))
                 return out
             if self._alternate(cons):
                 _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
@@ -233,9 +228,11 @@ class StereoASW():
             _raise_native(e)
         return out
 
-    def _compute_device(self, t1, t2, out_row0=0, out_rows=None):
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None, row_parity=0):
         """Operands already in HBM (torch tensors): returns a torch.int16 tensor on the device.
-        Rows [out_row0, out_row0+out_rows) of the given (sub-)image are matched."""
+        Rows [out_row0, out_row0+out_rows) of the given (sub-)image are matched.  ``row_parity`` (alternate=True only):
+        parity of the sub-image's first row in the whole image, whose even rows are the exactly matched ones; such a
+        sub-image carries ``winSize // 2 + 1`` halo rows."""
         import torch
         lib = _native.lib()
         win, maxd, mind, gc, gp, cons = self._params()
@@ -244,14 +241,15 @@ class StereoASW():
             raise ValueError("winSize must be a positive odd number!")
         H, W = int(a.shape[0]), int(a.shape[1])
         rows = H - out_row0 if out_rows is None else int(out_rows)
-        alt = self._alternate(cons, whole_image=(out_row0 == 0 and rows == H))
+        alt = self._alternate(cons)
         out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
         with torch.cuda.device(a.device):
             stream = torch.cuda.current_stream(a.device).cuda_stream
             try:
                 if alt:
-                    _native.check(lib.ssamd_asw_alternate_device(a.data_ptr(), b.data_ptr(), H, W, win, maxd, mind,
-                                                                 gc, gp, cons, out.data_ptr(), ctypes.c_void_p(stream)))
+                    _native.check(lib.ssamd_asw_alternate_rows_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows,
+                                                                      int(row_parity) & 1, win, maxd, mind, gc, gp, cons,
+                                                                      out.data_ptr(), ctypes.c_void_p(stream)))
                     return out
                 _native.check(lib.ssamd_asw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
                                                    maxd, mind, gc, gp, cons, out.data_ptr(),

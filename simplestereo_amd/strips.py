@@ -22,7 +22,7 @@ strips of the result are collected with one all_gather on equal-padded strips.
 """
 import numpy as np
 
-__all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip",
+__all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip", "matcher_pad",
            "StripContext"]
 
 
@@ -119,25 +119,34 @@ def gather_strips(strip_disparity, height, rank, world_size, group=None):
     return out
 
 
+def matcher_pad(matcher):
+    """Halo rows a strip of this matcher needs: winSize // 2, and one more for ``StereoASW(alternate=True)``, whose
+    odd rows take their candidates from the exactly matched rows above and below."""
+    return int(matcher.winSize) // 2 + (1 if getattr(matcher, "alternate", False) else 0)
+
+
 def match_strip(matcher, own_left, own_right, height, rank, world_size, group=None, gather=True):
     """One distributed `compute`: halo exchange -> kernels on the strip -> (optional) gather.
 
     matcher: a ``StereoASW`` / ``StereoGSW`` instance; the tensors must be device
     tensors (the kernels run on the tensors' GPU on the current stream).
     """
-    pad = int(matcher.winSize) // 2
+    pad = matcher_pad(matcher)
     subL, subR, out_row0, out_rows = exchange_halos(own_left, own_right, height, pad, rank, world_size, group)
-    strip = _match_rows(matcher, subL, subR, out_row0, out_rows)
+    r0, _ = strip_bounds(height, world_size, rank)
+    strip = _match_rows(matcher, subL, subR, out_row0, out_rows, (r0 - out_row0) & 1)
     return gather_strips(strip, height, rank, world_size, group) if gather else strip
 
 
-def _match_rows(matcher, subL, subR, out_row0, out_rows):
+def _match_rows(matcher, subL, subR, out_row0, out_rows, row_parity=0):
     """The kernels on one strip.  A rank whose strip is EMPTY (more ranks than image rows) has nothing to match --
     the operators refuse a 0-row image -- but must still take part in the collectives that follow, so it returns an
     empty int16 strip instead of raising while its peers wait in the all_gather."""
     import torch
     if out_rows <= 0:
         return torch.empty((0, int(subL.shape[1])), dtype=torch.int16, device=subL.device)
+    if getattr(matcher, "alternate", False):          # row_parity: parity of the sub-image's first row in the whole image
+        return matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows, row_parity=row_parity)
     return matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows)
 
 
@@ -164,7 +173,7 @@ class StripContext:
         self.flat_gather = backend == "nccl"                  # gloo has no all_gather_into_tensor
         self.staged = backend == "gloo" and self.device.type != "cpu"
         cdev = torch.device("cpu") if self.staged else self.device          # where messages live
-        self.pad = int(matcher.winSize) // 2
+        self.pad = matcher_pad(matcher)
         self.r0, self.r1 = strip_bounds(self.H, self.world, self.rank)
         self.h0, self.h1 = halo_bounds(self.H, self.r0, self.r1, self.pad)
         self.subL = torch.zeros((self.h1 - self.h0, self.W, 3), dtype=torch.uint8, device=self.device)
@@ -206,7 +215,7 @@ class StripContext:
                 for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
                     self.subL[lo:hi].copy_(tl)
                     self.subR[lo:hi].copy_(tr)
-        strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0)
+        strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0, self.h0 & 1)
         if not gather:
             return strip
         if self.world == 1 and not dist.is_initialized():

@@ -31,8 +31,6 @@ def test_signatures_match_reference(ss):
     assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
         ("winSize", 11), ("maxDisparity", 16), ("minDisparity", 0), ("gamma", 10), ("fMax", 120),
         ("iterations", 3), ("bins", 20), ("device", None)]
-    with pytest.raises(ValueError, match="whole image"):
-        ss.passive.StereoASW(alternate=True)._alternate(0, whole_image=False)
     assert ss.passive.StereoASW()._alternate(0) is False and ss.passive.StereoASW(alternate=True)._alternate(0) is True
     with pytest.raises(ValueError):
         ss.passive._device_index(-2)

@@ -73,8 +73,18 @@ def test_alternate_device_tensors_edges_and_errors(ss, golden_inputs):
     # empty candidate ranges give x, as in the exact mode (_passive.cpp:54,98)
     e = ss.passive.StereoASW(winSize=5, maxDisparity=3, minDisparity=7, alternate=True).compute(a, b)
     assert np.array_equal(e, np.tile(np.arange(a.shape[1], dtype=np.int16), (a.shape[0], 1)))
-    with pytest.raises(ValueError, match="whole image"):
-        m._compute_device(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), out_row0=2, out_rows=6)
+    # row ranges of the whole image and of sub-images with a halo of winSize/2 + 1 rows (round 2): the rows of the whole map
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    whole = m._compute_device(ta, tb)
+    H = a.shape[0]
+    pad = int(m.winSize) // 2 + 1
+    for r0, rows in ((2, 6), (3, 6), (3, 7), (0, 5), (H - 5, 5), (H - 4, 4), (1, 1), (7, 2)):
+        assert torch.equal(m._compute_device(ta, tb, out_row0=r0, out_rows=rows), whole[r0:r0 + rows]), (r0, rows)
+        h0, h1 = max(0, r0 - pad), min(H, r0 + rows + pad)
+        sub = m._compute_device(ta[h0:h1].contiguous(), tb[h0:h1].contiguous(), out_row0=r0 - h0, out_rows=rows, row_parity=h0 & 1)
+        assert torch.equal(sub, whole[r0:r0 + rows]), (r0, rows, h0)
+    with pytest.raises(ValueError):              # an odd first row needs the exact row above it inside the sub-image
+        m._compute_device(ta[1:].contiguous(), tb[1:].contiguous(), out_row0=0, out_rows=4, row_parity=1)
 
 
 def test_alternate_quality_on_tsukuba_is_not_worse(ss, golden_inputs):

@@ -67,8 +67,8 @@ def test_devices_argument_errors(golden_inputs):
         m.compute(a, b, devices=[])
     with pytest.raises(ValueError):
         m.compute(a, b, devices=[-1])
-    with pytest.raises(ValueError, match="whole image"):
-        ss.passive.StereoASW(winSize=7, maxDisparity=6, alternate=True).compute(a, b, devices=[0])
+    alt = ss.passive.StereoASW(winSize=7, maxDisparity=6, alternate=True)
+    assert np.array_equal(alt.compute(a, b, devices=[0]), alt.compute(a, b))      # (round 2: the alternate-rows mode takes strips)
     with pytest.raises(ValueError, match="host arrays"):
         m.compute(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), devices=[0])
 
@@ -129,3 +129,17 @@ def test_threads_on_one_device_still_serialise_correctly(golden_inputs):
     for t in ts:
         t.join()
     assert not errs
+
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_alternate_rows_mode_across_strips(n, allow_repeat, golden_inputs):
+    """StereoASW(alternate=True) cut into row strips (halo of winSize/2 + 1 rows, even rows of the WHOLE image exact
+    whatever row a strip starts at) gives the whole-image map bit for bit"""
+    import simplestereo_amd as ss
+    a, b = golden_inputs("synth_96x128")
+    for rows in (96, 95, 7):
+        aa, bb = np.ascontiguousarray(a[:rows]), np.ascontiguousarray(b[:rows])
+        m = ss.passive.StereoASW(winSize=9, maxDisparity=20, minDisparity=1, alternate=True)
+        want = m.compute(aa, bb)
+        assert np.array_equal(m.compute(aa, bb, devices=_devices(n)), want), (n, rows)

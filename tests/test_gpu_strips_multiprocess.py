@@ -53,6 +53,7 @@ def _worker(rank, world, port, case, q):
     (2, ("asw", 61, 200, dict(winSize=21, maxDisparity=40, consistent=True))),
     (3, ("asw", 50, 160, dict(winSize=35, maxDisparity=24, minDisparity=2))),      # strips thinner than the halo
     (2, ("gsw", 45, 150, dict(winSize=11, maxDisparity=30))),
+    (3, ("asw", 47, 160, dict(winSize=11, maxDisparity=24, alternate=True))),      # strips of 16 / 16 / 15 rows: odd and even starts
 ])
 def test_strips_across_processes_reproduce_the_whole_frame(world, case):
     import torch.multiprocessing as mp
