@@ -39,6 +39,10 @@
 #pragma once
 #include "asw_kernels.hip.h"
 
+#ifndef SSAMD_PIPE_SENTINEL       // 0: the round-2 weight build with masks (A/B builds of tools/build_variants.sh)
+#define SSAMD_PIPE_SENTINEL 1
+#endif
+
 namespace ssamd {
 
 // K0e: the truncated absolute differences e[r][u][d] = min(40, |dB|+|dG|+|dR|) of L[r][u] and R[r][u-d]
@@ -181,8 +185,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
             const bool isL = k < nL;
             const int idx = isL ? k : k - nL;
             const int col = (isL ? segL_lo : segR_lo) + idx;
+            // a tap column outside the image gets L = +inf: colour distance +inf, exp2(-inf) = +0 -- the weight 0 the
+            // reference's bounds test gives (_passive.cpp:60-62), exactly and without a mask in the weight build
             PixRec v;
-            v.L = v.a = v.b = 0.f;
+            v.L = SSAMD_PIPE_SENTINEL ? __builtin_inff() : 0.f;
+            v.a = v.b = 0.f;
             v.bgrx = 0u;
             if ((unsigned)col < (unsigned)W) v = (isL ? rowL : rowR)[col];
             (isL ? labL + buf * nL : labR + buf * nR)[idx] = make_float4(v.L, v.a, v.b, 0.f);
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     };
     // support weights of window row i, tap columns [jb, je), into weight buffer rows rb.. (_passive.cpp:47-50, 71-74;
     // exp(-dist/gammaC) = exp2(dist*kC)).  One thread per window centre, all columns of the chunk: batches of ASW_WB
-    // independent chains walking running pointers; taps or centres outside the image get weight 0 through a mask.
+    // independent chains walking running pointers; tap columns outside the image are staged with L = +inf and get weight +0
+    // (centres outside the image only feed candidates the winner-take-all never looks at).
     auto build_weights = [&](int i, int jb, int je, int rb) {
         int tidw = threadIdx.x;
         asm volatile("" : "+v"(tidw));
@@ -288,8 +296,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
                 for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
 #pragma unroll
                 for (int u = 0; u < ASW_WB; ++u) {
-                    const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
-                    wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                    if constexpr (SSAMD_PIPE_SENTINEL) {
+                        wp[u * stride] = pr[u] * wv[u];
+                    } else {
+                        const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
+                        wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                    }
                 }
             }
             if (j < je_t) {
@@ -314,8 +326,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
 #pragma unroll
                 for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
                     const int jj = min(j + u, je_t - 1);
-                    const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
-                    wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                    if constexpr (SSAMD_PIPE_SENTINEL) {
+                        wout[jj * stride] = pr[u] * wv[u];
+                    } else {
+                        const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
+                        wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                    }
                 }
             }
         }
