@@ -203,6 +203,26 @@ def test_asw_phase_shifted_kernel_equals_the_plain_one(geom, win, ss, golden_inp
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("shape,win,maxd", [((48, 200), 35, 60), ((36, 1000), 27, 150), ((30, 2000), 35, 192)])
+def test_asw_tad_volume_equals_the_in_kernel_e_tiles(shape, win, maxd, ss):
+    """the phase-shifted kernel fed by LDS-DMA from the pre-computed TAD volume (asw_tad_volume_kernel: 16-byte stores,
+    rows of whole 16-byte blocks) computes the map of the same kernel building its e tiles itself (SSAMD_ASW_EVOL=0)"""
+    import torch
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    H, W = shape
+    L, R, _ = make_pair(H, W, maxd, 21)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    assert _native.asw_kernel_form(W, H, win, maxd, 0)["phase_shifted"] == 1
+    m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, consistent=True)
+    want = m.compute(tL, tR)
+    try:
+        os.environ["SSAMD_ASW_EVOL"] = "0"
+        assert torch.equal(m.compute(tL, tR), want)
+    finally:
+        os.environ.pop("SSAMD_ASW_EVOL", None)
+
+
 @pytest.mark.parametrize("win,maxd,mind,consistent", [(35, 16, 0, False), (35, 16, 0, True), (21, 7, 0, True), (9, 3, 0, False),
                                                        (15, 1, 1, True), (1, 12, 0, True), (5, 47, 0, True), (17, 36, 5, True),
                                                        (11, 23, 9, True), (63, 20, 2, False)])
