@@ -28,7 +28,8 @@ def build(force=False):
     if force or not os.path.exists(_LIB) or \
             os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "oracle_passive.c")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_passive.so"])
-    if os.path.exists("/root/reference/simplestereo/_passive.cpp") and (force or ref_module() is None):
+    if os.path.exists("/root/reference/simplestereo/_passive.cpp") and (
+            force or ref_module() is None or not os.path.exists(os.path.join(_HERE, "_ref", "libref_lab.so"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 
@@ -144,6 +145,22 @@ def bgr2lab(img):
     H, W = a.shape[:2]
     lab = np.empty((H, W, 3), np.float64)
     lib.oracle_bgr2lab(_u8(a), lab.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), W, H)
+    return lab
+
+
+def ref_bgr2lab(img):
+    """The reference's OWN ColorConversion::ImageFromBGR2Lab (headers/colorconversion.hpp:81-86), compiled where it
+    lies behind oracle/ref_lab_harness.cpp into oracle/_ref/libref_lab.so; None when that file is absent."""
+    path = os.path.join(_HERE, "_ref", "libref_lab.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.ref_bgr2lab.restype = None
+    lib.ref_bgr2lab.argtypes = [ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
+    a = _img(img)
+    H, W = a.shape[:2]
+    lab = np.empty((H, W, 3), np.float64)
+    lib.ref_bgr2lab(_u8(a), lab.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), W, H)
     return lab
 
 

@@ -130,6 +130,27 @@ def test_oracle_lab_known_values():
     assert np.allclose(lab[3], [32.2970, 79.1875, -107.8602], atol=2e-2)  # pure blue
 
 
+def test_oracle_lab_bit_exact_vs_reference_header():
+    """oracle_bgr2lab == the reference's OWN ColorConversion::ImageFromBGR2Lab (headers/colorconversion.hpp:81-86) bit
+    for bit over the 636 056 colours of the step-3 byte cube: against the committed hash + sample recorded from the
+    reference header (tests/golden/make_golden_lab.py) on every box, and against the compiled header itself
+    (oracle/_ref/libref_lab.so, oracle/ref_lab_harness.cpp) where it is present."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden_lab
+    meta = json.load(open(os.path.join(GOLDEN, "lab_cube.json")))
+    img = make_golden_lab.cube(meta["step"])
+    assert img.shape[1] == meta["colours"]
+    lab = oracle.bgr2lab(img)
+    assert hashlib.sha256(lab.tobytes()).hexdigest() == meta["sha256_float64"]
+    sample = np.load(os.path.join(GOLDEN, "lab_cube_sample.npz"))
+    assert np.array_equal(img[0, sample["index"]], sample["bgr"])
+    assert np.array_equal(lab[0, sample["index"]], sample["lab"])
+    ref = oracle.ref_bgr2lab(img)
+    if ref is not None:
+        assert np.array_equal(ref, lab)
+
+
 def test_reference_module_agrees_when_present(golden_cases, golden_inputs):
     ref = oracle.ref_module()
     if ref is None:
