@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSAMD_ABI_VERSION 1
+#define SSAMD_ABI_VERSION 2      /* 2: ssamd_set_option, ssamd_asw_gsw_host staging (round 3); the multi-device and verification entry points of round 2 */
 
 #define SSAMD_OK 0
 #define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
@@ -197,6 +197,12 @@ int ssamd_profile_enable(int on);
 int ssamd_profile_reset(void);
 int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);
 const char *ssamd_kernel_name(int slot);
+
+/* Experiment / test hooks.  The SSAMD_* environment variables (SSAMD_ASW_GEOM, SSAMD_ASW_PIPE,
+ * SSAMD_ASW_WAVE, ... -- the same names are the option names here) are read once, when the library is loaded; this
+ * call changes one of them afterwards (value NULL = unset).  No operator call reads the environment.  None of the
+ * options changes a disparity map: that is what the tests using them assert.  SSAMD_EINVAL for an unknown name. */
+int ssamd_set_option(const char *name, const char *value);
 
 /* Autotuning of the ASW launch geometry.  When it applies, the first ssamd_asw* call for a problem shape (width,
  * rows, winSize, number of disparities) times the best tile of every class of candidates on the call's own

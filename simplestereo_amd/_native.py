@@ -9,8 +9,15 @@ import os
 
 from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
-# experiments only (tools/build_variants.sh): load another build of the same library
-LIB_PATH = os.environ.get("SSAMD_LIB") or _DEFAULT_LIB_PATH
+# experiments only (tools/build_variants.sh): another build of the same library is loaded only when the caller says
+# twice that this is an experiment -- ablation builds compute wrong maps by construction
+LIB_PATH = _DEFAULT_LIB_PATH
+if os.environ.get("SSAMD_LIB"):
+    if os.environ.get("SSAMD_EXPERIMENT") != "1":
+        raise ImportError("SSAMD_LIB is an experiment hook: set SSAMD_EXPERIMENT=1 as well to load %s instead of the product "
+                          "library" % os.environ["SSAMD_LIB"])
+    LIB_PATH = os.environ["SSAMD_LIB"]
+ABI_VERSION = 2
 
 K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_ASW_ALT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -44,9 +51,13 @@ def lib():
     # second sees no device.
     try:
         import torch  # noqa: F401
-    except ImportError:
+    except Exception:      # noqa: BLE001 -- absent or broken torch: host-array calls do not need it
         pass
     L = ctypes.CDLL(LIB_PATH)
+    L.ssamd_abi_version.restype = ctypes.c_int
+    if L.ssamd_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this package needs %d: rebuild it with `python -m simplestereo_amd.build`"
+                          % (LIB_PATH, L.ssamd_abi_version(), ABI_VERSION))
     I, D, F, P = ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_void_p
     L.ssamd_abi_version.restype = I
     L.ssamd_last_error.restype = ctypes.c_char_p
@@ -98,10 +109,33 @@ def lib():
     L.ssamd_asw_kernel_form.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
     L.ssamd_gsw_geometry.restype = I
     L.ssamd_gsw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
-    if L.ssamd_abi_version() != 1:
-        raise ImportError("libssamd ABI version mismatch")
+    L.ssamd_set_option.restype = I
+    L.ssamd_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     _lib = L
     return L
+
+
+def set_option(name, value):
+    """Experiment / test hook: set (or, with None, unset) one of the SSAMD_* tuning options of the loaded library.
+    The environment variables of the same names are only read when the library is loaded."""
+    check(lib().ssamd_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+class options:
+    """``with _native.options(SSAMD_ASW_GEOM="3,5,8"): ...`` -- set tuning options for a block, unset them afterwards."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None)
+        return False
 
 
 def check(rc):

@@ -110,9 +110,11 @@ def _remap(img, mapx, mapy, interpolation=INTER_LINEAR):
     INTER_BITS = 5; ``initInterTab2D`` builds 15-bit integer weights, INTER_REMAP_COEF_BITS = 15 -- with 5-bit
     fractions they are exactly a*b*32 and sum to 32768; ``remapBilinear`` for uint8 ends in
     ``FixedPtCast<int, uchar, 15>``: ``(sum + (1 << 14)) >> 15``, so ties round UP, not to even).
-    Integer images take that fixed-point path, with the common factor 32 divided out: ``(S + 512) >> 10``;
-    float images blend in floating point like OpenCV's float path.  cv2 is absent in this environment: parity
-    with cv2.remap itself stays unpinned (reference call: _rigs.py:564-565)."""
+    uint8 images take that fixed-point path, with the common factor 32 divided out: ``(S + 512) >> 10``.  Every other
+    dtype goes the way of OpenCV's non-uchar instantiations: float32 weights ``(1-fy)(1-fx)`` ... from the 1/32-pixel
+    fractions, a float32 sum in tap order, and for uint16 / int16 ... ``saturate_cast`` = round half to EVEN
+    (``np.rint``) + clip; float images keep the float sum.  cv2 is absent in this environment: parity with cv2.remap
+    itself stays unpinned here (reference call: _rigs.py:564-565) -- tests/test_cv2_pins.py pins it wherever cv2 exists."""
     img = np.asarray(img)
     squeeze = img.ndim == 2
     src = img[:, :, None] if squeeze else img
@@ -128,20 +130,25 @@ def _remap(img, mapx, mapy, interpolation=INTER_LINEAR):
         r = np.rint(mapy.astype(np.float64) * 32).astype(np.int64)
         x0, fx = q >> 5, q & 31
         y0, fy = r >> 5, r & 31
-        integer = np.issubdtype(src.dtype, np.integer)
-        acc = np.zeros(mapx.shape + (src.shape[2],), np.int64 if integer else np.float64)
+        fixed = src.dtype == np.uint8                       # OpenCV's 15-bit FixedPtCast path exists for uchar only
+        acc = np.zeros(mapx.shape + (src.shape[2],), np.int64 if fixed else (np.float64 if src.dtype == np.float64 else np.float32))
         for dy, wy in ((0, 32 - fy), (1, fy)):
             for dx, wx in ((0, 32 - fx), (1, fx)):
                 xx, yy = x0 + dx, y0 + dy
                 ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
                 val = np.zeros_like(acc)
                 val[ok] = src[yy[ok], xx[ok]]
-                acc += val * (wy * wx)[..., None]          # a*b in 0..1024
-        if integer:
+                if fixed:
+                    acc += val * (wy * wx)[..., None]      # a*b in 0..1024
+                else:                                       # float32 weights a*b/1024 (exact), float32 products and sum
+                    acc = acc + val * ((wy * wx).astype(np.float32) * np.float32(1.0 / 1024.0)).astype(acc.dtype)[..., None]
+        if fixed:
+            out = np.clip((acc + 512) >> 10, 0, 255).astype(np.uint8)
+        elif np.issubdtype(src.dtype, np.integer):
             info = np.iinfo(src.dtype)
-            out = np.clip((acc + 512) >> 10, info.min, info.max).astype(src.dtype)
+            out = np.clip(np.rint(acc), info.min, info.max).astype(src.dtype)      # saturate_cast: ties to even
         else:
-            out = (acc / 1024.0).astype(src.dtype)
+            out = acc.astype(src.dtype)
     else:
         raise NotImplementedError("only INTER_NEAREST (0) and INTER_LINEAR (1) are available without OpenCV")
     return np.ascontiguousarray(out[:, :, 0] if squeeze else out)

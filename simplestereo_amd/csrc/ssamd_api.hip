@@ -48,6 +48,75 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// Experiment / test hooks.  The SSAMD_* environment variables are read ONCE, when the library is
+// loaded; afterwards the table only changes through ssamd_set_option (tests, tools).  The host path of an operator
+// call never calls getenv: it reads a thread-local snapshot that is refreshed when the table's version moves.
+struct Tuning {
+    std::string asw_geom, gsw_geom;   // "XG,DG[,JC[,RX]]" / "XG,DG[,Ty]": forced launch geometry ("" = unset)
+    int asw_pipe = -1;                // -1 unset, 0: phase-shifted kernel off, 8 / 16: forced chunk length
+    int asw_dephase = -1;             // -1 unset, else the wave order of the phase-shifted kernel
+    int asw_evol = 1;                 // 0: in-kernel e tiles instead of the TAD volume
+    int asw_wave = -1;                // -1 unset, 0: small-range wave kernel off (any set value bypasses cache and tuner)
+    int wave_rx = 0;                  // 0 unset, 8 / 4: forced register tile of the wave kernel
+    int wave_wg = 0;                  // 0 unset (one wave per workgroup), 1..4
+    int wave_unroll = 1;              // 0: counted build loop
+    int wave_merge = 1;               // 0: left and right centres of a strip in separate build rounds (round-2 form)
+    bool no_e2 = false, xor_only = false, multi_allow_repeat = false;
+    int alt_queue_cap = 0;            // 0 unset
+    int autotune_env = -2;            // -2 unset
+};
+std::mutex g_tune_mutex;
+std::atomic<unsigned> g_tune_version{1};
+
+bool tuning_assign(Tuning &t, const std::string &name, const char *v)
+{
+    auto num = [&](int unset) { return v ? atoi(v) : unset; };
+    if (name == "SSAMD_ASW_GEOM") t.asw_geom = v ? v : "";
+    else if (name == "SSAMD_GSW_GEOM") t.gsw_geom = v ? v : "";
+    else if (name == "SSAMD_ASW_PIPE") t.asw_pipe = num(-1);
+    else if (name == "SSAMD_ASW_DEPHASE") t.asw_dephase = num(-1);
+    else if (name == "SSAMD_ASW_EVOL") t.asw_evol = num(1);
+    else if (name == "SSAMD_ASW_WAVE") t.asw_wave = v ? (atoi(v) != 0 ? 1 : 0) : -1;
+    else if (name == "SSAMD_ASW_WAVE_RX") t.wave_rx = num(0);
+    else if (name == "SSAMD_ASW_WAVE_WG") t.wave_wg = v ? std::max(1, std::min(4, atoi(v))) : 0;
+    else if (name == "SSAMD_ASW_WAVE_UNROLL") t.wave_unroll = num(1);
+    else if (name == "SSAMD_ASW_WAVE_MERGE") t.wave_merge = num(1);
+    else if (name == "SSAMD_ASW_NO_E2") t.no_e2 = v != nullptr;
+    else if (name == "SSAMD_ASW_XOR_ONLY") t.xor_only = v != nullptr;
+    else if (name == "SSAMD_MULTI_ALLOW_REPEAT") t.multi_allow_repeat = v != nullptr;
+    else if (name == "SSAMD_ALT_QUEUE_CAP") t.alt_queue_cap = v ? std::max(1, atoi(v)) : 0;
+    else if (name == "SSAMD_AUTOTUNE") t.autotune_env = v ? (atoi(v) > 0 ? 1 : (atoi(v) < 0 ? -1 : 0)) : -2;
+    else return false;
+    return true;
+}
+
+const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
+                                    "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
+                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE"};
+
+Tuning tuning_from_env()
+{
+    Tuning t;
+    for (const char *n : kTuningNames)
+        if (const char *v = getenv(n)) (void)tuning_assign(t, n, v);      // the only getenv calls of the library
+    return t;
+}
+Tuning g_tuning = tuning_from_env();
+
+const Tuning &tune()
+{
+    thread_local Tuning snap;
+    thread_local unsigned seen = 0;
+    const unsigned v = g_tune_version.load(std::memory_order_acquire);
+    if (v != seen) {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        snap = g_tuning;
+        seen = v;
+    }
+    return snap;
+}
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -69,6 +138,11 @@ struct DevBuf {
         if (e != hipSuccess) { ptr = nullptr; return fail(SSAMD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
         cap = want;
         return SSAMD_OK;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
     }
 };
 
@@ -257,7 +331,7 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
         g.pipe = 1;
         // waves 0-3 build before they aggregate (see the kernel): pays with three or four waves per SIMD (12-wave
         // groups: 1080p/193 41.8 -> 41.0 ms), costs with two (640x480/65, 8 waves: 3.11 -> 3.26 ms)
-        g.dephase = getenv("SSAMD_ASW_DEPHASE") ? atoi(getenv("SSAMD_ASW_DEPHASE")) : (round_up(XG * DG, 64) / 64 >= 12 ? 1 : 0);
+        g.dephase = tune().asw_dephase >= 0 ? tune().asw_dephase : (round_up(XG * DG, 64) / 64 >= 12 ? 1 : 0);
         g.JCmax = std::max(JC, win - (g.NC - 1) * JC);
     }
     const int wrows = g.pipe ? 2 * g.JCmax : (g.JC < win ? 2 * g.JC : win);   // chunk buffers alternate
@@ -330,7 +404,7 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
 // LDS budget they fall back to one.
 bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20, int Rx = ASW_RX, bool odd_pitch = false)
 {
-    if (!getenv("SSAMD_ASW_NO_E2") && asw_layout_e(g, win, XG, DG, limit, JC, Rx, true, odd_pitch) && g.e2) return true;
+    if (!tune().no_e2 && asw_layout_e(g, win, XG, DG, limit, JC, Rx, true, odd_pitch) && g.e2) return true;
     return asw_layout_e(g, win, XG, DG, limit, JC, Rx, false, odd_pitch);
 }
 
@@ -359,7 +433,7 @@ double asw_e_read_passes(const AswGeom &g)
 // tile, or when it does not read slower.
 void asw_pick_e_scheme(AswGeom &g, int win)
 {
-    if (getenv("SSAMD_ASW_XOR_ONLY")) return;
+    if (tune().xor_only) return;
     AswGeom alt;
     if (!asw_layout(alt, win, g.XG, g.DG, 160 * 1024, g.JC >= win ? (1 << 20) : g.JC, g.Rx, true)) return;
     // two e tiles (one barrier less per window row: 1080p/193 45.96 -> 44.7 ms) outweigh a few bank conflicts of a
@@ -377,8 +451,7 @@ void asw_pick_e_scheme(AswGeom &g, int win)
 // SSAMD_ASW_PIPE=0 disables it, =8 / =16 force the chunk length (experiments and tests).
 void asw_try_pipe(AswGeom &g, int win)
 {
-    int want = -1;
-    if (const char *env = getenv("SSAMD_ASW_PIPE")) want = atoi(env);
+    const int want = tune().asw_pipe;
     if (want == 0 || g.Rx != 8) return;
     for (int JC : {16, 8}) {
         if (want > 0 && JC != want) continue;
@@ -415,7 +488,7 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
     // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
     // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
     g.Se = 4 * (g.DG | 1);
-    g.waves = getenv("SSAMD_ASW_WAVE_WG") ? std::max(1, std::min(4, atoi(getenv("SSAMD_ASW_WAVE_WG")))) : 1;
+    g.waves = tune().wave_wg ? tune().wave_wg : 1;
     // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
     // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
     size_t off = 0;
@@ -441,12 +514,10 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
 static constexpr int ASW_WAVE_MAX_ND = 48;
 int asw_wave_pick(int win, int nD)
 {
-    if (getenv("SSAMD_ASW_WAVE") && atoi(getenv("SSAMD_ASW_WAVE")) == 0) return 0;
-    if (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0) return 0;
+    if (tune().asw_wave == 0 || tune().asw_evol == 0) return 0;
     if (nD < 1 || nD > ASW_WAVE_MAX_ND || win > 63) return 0;
     AswWaveGeom wg;
-    if (const char *env = getenv("SSAMD_ASW_WAVE_RX")) {
-        const int rx = atoi(env);
+    if (const int rx = tune().wave_rx) {
         return (rx == 8 || rx == 4) && asw_wave_layout(wg, win, nD, rx) ? rx : 0;
     }
     const int first = nD <= 16 ? 4 : 8, second = 12 - first;
@@ -472,11 +543,16 @@ std::map<std::array<int, 4>, AswGeom> g_asw_geom_cache;
 std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached geometry was picked by measurement
 // autotuning mode: 1 always, 0 never, -1 (default) only for small problems, where the ~50 trial launches cost
 // at most about 0.2 s once and where the cost model is least reliable
-std::atomic<int> g_autotune{getenv("SSAMD_AUTOTUNE") ? (atoi(getenv("SSAMD_AUTOTUNE")) > 0 ? 1 : (atoi(getenv("SSAMD_AUTOTUNE")) < 0 ? -1 : 0)) : -1};
+std::atomic<int> g_autotune{g_tuning.autotune_env != -2 ? g_tuning.autotune_env : -1};
 constexpr double ASW_AUTOTUNE_SMALL_TAPS = 3.0e10;      // window taps per call (about 3-4 ms of kernel time)
 
 // experiment / test hooks that force a kernel form: such calls neither read nor write the geometry cache and are not autotuned
-bool asw_geometry_forced() { return getenv("SSAMD_ASW_GEOM") || getenv("SSAMD_ASW_WAVE") || getenv("SSAMD_ASW_WAVE_RX"); }
+bool asw_geometry_forced()
+{
+    const Tuning &t = tune();
+    return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
+           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only;
+}
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
 {
@@ -499,9 +575,9 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
 {
     std::map<std::array<int, 4>, std::pair<double, AswGeom>> classes;
     // tuning hook: SSAMD_ASW_GEOM="XG,DG[,JC[,RX]]" forces the tile shape (experiments and tests only)
-    if (const char *env = getenv("SSAMD_ASW_GEOM")) {
+    if (!tune().asw_geom.empty()) {
         int XG = 0, DG = 0, JCe = 1 << 20, Rx = ASW_RX;
-        if (sscanf(env, "%d,%d,%d,%d", &XG, &DG, &JCe, &Rx) >= 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS &&
+        if (sscanf(tune().asw_geom.c_str(), "%d,%d,%d,%d", &XG, &DG, &JCe, &Rx) >= 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS &&
             (Rx == 8 || Rx == 4)) {
             if (JCe <= 0 || JCe % Rx) JCe = 1 << 20;
             if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe, Rx)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
@@ -527,7 +603,7 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         if (Rx == 4 && nD > 56) continue;
         const int max_wps = Rx == 8 ? 3 : 4;
         const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + Rx - 1) / Rx);
-        const int pipe_env = getenv("SSAMD_ASW_PIPE") ? atoi(getenv("SSAMD_ASW_PIPE")) : -1;
+        const int pipe_env = tune().asw_pipe;
         for (int XG = xg_cap; XG >= 1; --XG)
         for (int cand = 0; cand < 6; ++cand) {
             // candidates 0-3: asw_aggregate_kernel with whole window rows or tap-column chunks of 16 / 8 / 4;
@@ -606,7 +682,7 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
         if (wave_rx) {          // the model's choice first, then the other tile of the wave kernel, then workgroup geometries
             shortlist->push_back(best);
             AswWaveGeom wg;
-            if (!getenv("SSAMD_ASW_WAVE_RX") && asw_wave_layout(wg, win, nD, 12 - wave_rx)) {
+            if (!tune().wave_rx && asw_wave_layout(wg, win, nD, 12 - wave_rx)) {
                 AswGeom other = best;
                 other.wave_rx = 12 - wave_rx;
                 shortlist->push_back(other);
@@ -711,7 +787,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
 
     // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
     // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
-    AswArgs a;
+    AswArgs a{};
     const int grows = alternate ? (rows + 1) / 2 : rows;              // workgroup rows: every row, or the even ones
     if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, grows, win, nD))) return rc;
     // Autotuning (ssamd_autotune): the first call for a problem shape times the best geometry of every class of
@@ -766,18 +842,31 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             if (g.wave_rx) {
                 if (!asw_wave_layout(wa.g, win, nD, g.wave_rx)) return fail(SSAMD_ELIMIT, "wave kernel geometry does not fit LDS");
                 chunks = 1; Tx = wa.g.Txw; Dc = wa.g.Dc; Se = wa.g.Se;
-            } else if (!g.pipe || (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0)) {
+            } else if (!g.pipe || tune().asw_evol == 0) {
                 return SSAMD_OK;
             }
             const int xt = (W + Tx - 1) / Tx;
             const int evolW = round_up(xt * Tx + 2 * p, 4);           // rows stay 16-byte aligned for any Se
             const size_t bytes = (size_t)chunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)Se;
-            if (bytes > ((size_t)24 << 30)) {
-                if (g.wave_rx) return fail(SSAMD_ELIMIT, "TAD volume of %zu bytes is too large", bytes);
-                return SSAMD_OK;                                      // very large frames: build the tiles in the kernel
+            // The volume is scratch of THIS library next to the caller's own allocations (torch's caching allocator on
+            // the same GPU): never more than 24 GiB, never more than half of what is free right now (plus what the
+            // buffer already holds), and a buffer four times larger than a later call needs is given back.
+            size_t free_b = 0, total_b = 0;
+            size_t limit = (size_t)24 << 30;
+            if (bytes + 4096 > c.evol.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                limit = std::min(limit, c.evol.cap + free_b / 2);
+            if (c.evol.cap > ((size_t)256 << 20) && (bytes + 4096) * 4 < c.evol.cap) {
+                (void)hipStreamSynchronize(s);                        // (earlier launches of this call may still read it)
+                c.evol.release();
             }
-            int erc = c.evol.reserve(bytes + 4096);                     // + one DMA piece of slack behind the last tile
-            if (erc) return erc;
+            int erc = bytes <= limit ? c.evol.reserve(bytes + 4096) : SSAMD_ENOMEM;     // + one DMA piece of slack behind the last tile
+            if (erc) {
+                // the phase-shifted kernel builds its e tiles itself when there is no volume (A.evol == nullptr);
+                // only the wave kernel cannot run without one
+                if (g.wave_rx) return fail(erc == SSAMD_ENOMEM ? SSAMD_ENOMEM : erc, "TAD volume of %zu bytes does not fit the device memory left", bytes);
+                g_err.clear();
+                return SSAMD_OK;
+            }
             a.evol = (const unsigned char *)c.evol.ptr;
             a.evolW = evolW;
             Timed t(c, s, SSAMD_K_LAB);
@@ -802,7 +891,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                                        : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
                 // build rounds known at compile time (straight-line build): the common combinations
                 const int kl = (wa.g.Txw + 63) / 64, kr = (wa.g.nRcw + 63) / 64;
-                const bool unrolled = !(getenv("SSAMD_ASW_WAVE_UNROLL") && atoi(getenv("SSAMD_ASW_WAVE_UNROLL")) == 0);
+                const bool unrolled = tune().wave_unroll != 0;
                 if (unrolled && !d_costs) {
                     const int key = wa.g.RX * 100 + kl * 10 + kr;
                     if (key == 822) wk = asw_aggregate_wave_kernel<false, 8, 2, 2>;         // 17..28 disparities (class default)
@@ -884,8 +973,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         if ((double)nodd * ((nD + 7) / 8 + 1) >= 4.0e9)
             return fail(SSAMD_ELIMIT, "alternate-rows mode: image x disparity range too large for the 32-bit job counter");
         f.cap = (unsigned int)std::min<size_t>(std::max<size_t>(nodd, 1 << 16), 1u << 28);   // jobs of 8 candidates
-        if (const char *env = getenv("SSAMD_ALT_QUEUE_CAP"))        // test hook: a tiny queue forces the in-place path
-            f.cap = (unsigned int)std::max(1, atoi(env));
+        if (tune().alt_queue_cap)                                   // test hook: a tiny queue forces the in-place path
+            f.cap = (unsigned int)tune().alt_queue_cap;
         if ((rc = c.altq.reserve((size_t)f.cap * 8 + 16))) return rc;
         f.ctr = (unsigned int *)c.altq.ptr; f.queue = (u64 *)((char *)c.altq.ptr + 16);
         HIP_TRY(hipMemsetAsync(f.ctr, 0, 16, s));
@@ -963,7 +1052,7 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD);
 int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)      // cached like asw_choose_geometry
 {
     static std::map<std::array<int, 4>, GswGeom> cache;
-    if (getenv("SSAMD_GSW_GEOM")) return gsw_search_geometry(best, W, rows, win, nD);
+    if (!tune().gsw_geom.empty()) return gsw_search_geometry(best, W, rows, win, nD);
     std::lock_guard<std::mutex> glk(g_geom_mutex);
     const std::array<int, 4> key{W, rows, win, nD};
     auto it = cache.find(key);
@@ -978,7 +1067,8 @@ int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)      //
 
 int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
 {
-    if (const char *env = getenv("SSAMD_GSW_GEOM")) {           // experiment hook: "XG,DG,Ty"
+    if (!tune().gsw_geom.empty()) {                             // experiment hook: "XG,DG,Ty"
+        const char *const env = tune().gsw_geom.c_str();
         int XG = 0, DG = 0, Ty = 1;
         if (sscanf(env, "%d,%d,%d", &XG, &DG, &Ty) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) &&
             XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024)) {
@@ -1194,7 +1284,7 @@ int run_strips(const HostJob &job, const int *devices, int n_devices, int (*fn)(
         if (devices[a] < 0) return fail(SSAMD_EINVAL, "devices[%d] = %d: explicit non-negative ordinals only", a, devices[a]);
         // test hook SSAMD_MULTI_ALLOW_REPEAT: a 1-GPU box exercises the strip cut with one device listed several
         // times (the strips then simply queue on that device's mutex)
-        for (int b = 0; b < a && !getenv("SSAMD_MULTI_ALLOW_REPEAT"); ++b)
+        for (int b = 0; b < a && !tune().multi_allow_repeat; ++b)
             if (devices[a] == devices[b]) return fail(SSAMD_EINVAL, "device %d listed twice", devices[a]);
     }
     int rc = check_common(job.H, job.W, job.win, job.minD, job.maxD, 0, job.H);
@@ -1209,10 +1299,16 @@ int run_strips(const HostJob &job, const int *devices, int n_devices, int (*fn)(
         j.o1 = j.o0 + base + (k < extra ? 1 : 0);
         if (j.o1 <= j.o0) continue;                      // more devices than rows: nothing for this one
         const int dev = devices[k];
-        th.emplace_back([j, dev, k, fn, &codes, &msgs]() {
-            codes[k] = fn(j, dev);
-            if (codes[k]) msgs[k] = g_err;               // thread-local message of the worker
-        });
+        try {
+            th.emplace_back([j, dev, k, fn, &codes, &msgs]() {
+                codes[k] = fn(j, dev);
+                if (codes[k]) msgs[k] = g_err;           // thread-local message of the worker
+            });
+        } catch (const std::exception &e) {              // no exception may cross the C ABI: finish what runs, report
+            codes[k] = SSAMD_ENOMEM;
+            msgs[k] = std::string("could not start a host thread: ") + e.what();
+            break;
+        }
     }
     for (auto &t : th) t.join();
     for (int k = 0; k < n_devices; ++k)
@@ -1260,6 +1356,16 @@ const char *ssamd_kernel_name(int slot)
                                                "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
                                                "asw_alt_fill_kernel"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
+}
+
+int ssamd_set_option(const char *name, const char *value)
+{
+    if (!name) return fail(SSAMD_EINVAL, "option name is NULL");
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    if (!tuning_assign(g_tuning, name, value)) return fail(SSAMD_EINVAL, "unknown option %s", name);
+    if (std::string(name) == "SSAMD_AUTOTUNE" && value) g_autotune.store(g_tuning.autotune_env);
+    g_tune_version.fetch_add(1, std::memory_order_release);
+    return SSAMD_OK;
 }
 
 int ssamd_autotune(int on)

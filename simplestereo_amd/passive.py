@@ -24,7 +24,11 @@ Documented deviations that turn undefined behaviour of the reference into
 defined behaviour: ``img2``'s dtype is checked too (the reference tests ``img1``
 twice, ``_passive.cpp:309``), non-contiguous inputs are made contiguous (the
 reference reads them as if contiguous), negative ``minDisparity`` is rejected
-(out-of-bounds reads in the reference).
+(out-of-bounds reads in the reference), and ``StereoASW`` refuses ``gammaC <= 0`` / ``gammaP <= 0`` with
+``ValueError`` (the reference computes with any value, ``_passive.cpp:47-50``: a negative gamma turns the support
+weights into GROWING exponentials whose products overflow fp32 where the reference's fp64 does not, a zero gamma
+makes every cost NaN -- neither is a matcher anyone runs; ``StereoGSW`` accepts negative ``gamma`` like the
+reference, golden G9f).
 
 Extensions (not in the reference): ``compute`` also accepts two CUDA/HIP
 ``torch.uint8`` tensors ``[H,W,3]`` already resident in HBM and then returns a
@@ -184,6 +188,8 @@ class StereoASW():
     def _params(self):
         win, maxd, mind = _c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity)
         gc, gp = _c_double(self.gammaC), _c_double(self.gammaP)
+        if not (gc > 0 and gp > 0):          # documented deviation (module docstring)
+            raise ValueError("gammaC and gammaP must be positive")
         return win, maxd, mind, gc, gp, 1 if self.consistent else 0
 
     def _alternate(self, cons):

@@ -101,6 +101,14 @@ def test_compute_exceptions_match_reference_probes(ss, golden_errors, golden_inp
         asw(a, b.astype(np.float32))                      # reference checks img1 twice (_passive.cpp:309)
 
 
+@pytest.mark.parametrize("gc,gp", [(0, 17.5), (-5, 17.5), (5, 0), (5, -1.0), (float("nan"), 17.5)])
+def test_asw_rejects_non_positive_gammas(gc, gp, ss, golden_inputs):
+    """documented deviation: the reference computes with any gamma (_passive.cpp:47-50)"""
+    a, b = golden_inputs("crop")
+    with pytest.raises(ValueError, match="gammaC and gammaP must be positive"):
+        ss.passive.StereoASW(winSize=5, maxDisparity=4, gammaC=gc, gammaP=gp).compute(a, b)
+
+
 def test_c_abi_exports_every_declared_symbol(ss):
     from simplestereo_amd import _native
     lib = _native.lib()
@@ -110,8 +118,34 @@ def test_c_abi_exports_every_declared_symbol(ss):
             "ssamd_bgr2lab", "ssamd_last_error", "ssamd_device_count"} <= declared
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.ssamd_abi_version() == 1
+    m = re.search(r"#define SSAMD_ABI_VERSION (\d+)", header)
+    assert lib.ssamd_abi_version() == int(m.group(1)) == _native.ABI_VERSION
     assert "asw_aggregate" in lib.ssamd_kernel_name(1).decode()
+
+
+def test_experiment_library_override_needs_two_switches():
+    """SSAMD_LIB (ablation builds: wrong maps by construction) is refused unless SSAMD_EXPERIMENT=1 is set as well"""
+    import subprocess
+    import sys
+    env = dict(os.environ, SSAMD_LIB="/nonexistent/libssamd_ablation.so")
+    env.pop("SSAMD_EXPERIMENT", None)
+    r = subprocess.run([sys.executable, "-c", "import simplestereo_amd._native"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "SSAMD_EXPERIMENT=1" in r.stderr
+
+
+def test_tuning_options_are_a_table_not_the_environment(ss):
+    """the SSAMD_* hooks are read from the environment once, at load; afterwards only ssamd_set_option changes them
+    (no getenv on the per-call host path) and unknown names are refused"""
+    from simplestereo_amd import _native
+    src = open(os.path.join(ROOT, "simplestereo_amd", "csrc", "ssamd_api.hip")).read()
+    assert src.count("getenv(") == 1            # tuning_from_env, run once by the static initialiser
+    f0 = _native.asw_kernel_form(1920, 10, 35, 16, 0)
+    assert f0["wave_kernel"] in (4, 8)
+    with _native.options(SSAMD_ASW_WAVE="0"):
+        assert _native.asw_kernel_form(1920, 10, 35, 16, 0)["wave_kernel"] == 0
+    assert _native.asw_kernel_form(1920, 10, 35, 16, 0) == f0
+    with pytest.raises(_native.NativeError):
+        _native.set_option("SSAMD_NO_SUCH_OPTION", "1")
 
 
 def test_geometry_query_is_sane(ss):

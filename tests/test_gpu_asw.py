@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+from simplestereo_amd import _native      # noqa: E402  (tuning options: _native.set_option)
 
 pytestmark = pytest.mark.gpu
 
@@ -154,17 +155,17 @@ def test_asw_forced_geometries_and_chunked_staging_agree(geom, ss, golden_inputs
     maxd = int(geom.split(",")[1]) * 4 - 1        # geom = XG,DG[,JC[,RX]]: 4-column register tiles as well
     m = ss.passive.StereoASW(winSize=21, maxDisparity=maxd, minDisparity=0, consistent=True)
     want = m.compute(a, b)
-    os.environ["SSAMD_ASW_GEOM"] = geom
+    _native.set_option("SSAMD_ASW_GEOM", geom)
     try:
         got = m.compute(a, b)
         # the same tile without the second e tile (row-start barrier kept) and with the XOR-swizzled e rows only
-        os.environ["SSAMD_ASW_NO_E2"] = "1"
+        _native.set_option("SSAMD_ASW_NO_E2", "1")
         got_one_e = m.compute(a, b)
-        os.environ["SSAMD_ASW_XOR_ONLY"] = "1"
+        _native.set_option("SSAMD_ASW_XOR_ONLY", "1")
         got_xor = m.compute(a, b)
     finally:
         for k in ("SSAMD_ASW_GEOM", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY"):
-            os.environ.pop(k, None)
+            _native.set_option(k, None)
     assert np.array_equal(got, want)
     assert np.array_equal(got_one_e, want) and np.array_equal(got_xor, want)
 
@@ -188,19 +189,19 @@ def test_asw_phase_shifted_kernel_equals_the_plain_one(geom, win, ss, golden_inp
         c = np.empty((H, W, maxd), np.float32)
         _native.check(_native.lib().ssamd_asw_costs(a.ctypes.data, b.ctypes.data, H, W, win, maxd, 1, 7.0, 17.5, c.ctypes.data, -1))
         return c
-    os.environ["SSAMD_ASW_GEOM"] = "%d,%d,0,8" % (XG, DG)          # the tile, whole window rows, plain kernel
-    os.environ["SSAMD_ASW_PIPE"] = "0"
+    _native.set_option("SSAMD_ASW_GEOM", "%d,%d,0,8" % (XG, DG))          # the tile, whole window rows, plain kernel
+    _native.set_option("SSAMD_ASW_PIPE", "0")
     try:
         want, want_c = m.compute(a, b), costs()
         for dephase in ("0", "1"):
-            os.environ["SSAMD_ASW_PIPE"] = str(JC)
-            os.environ["SSAMD_ASW_DEPHASE"] = dephase
+            _native.set_option("SSAMD_ASW_PIPE", str(JC))
+            _native.set_option("SSAMD_ASW_DEPHASE", dephase)
             got, got_c = m.compute(a, b), costs()
             assert np.array_equal(got, want), (geom, win, dephase)
             assert np.array_equal(got_c, want_c, equal_nan=True), (geom, win, dephase)
     finally:
         for k in ("SSAMD_ASW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE"):
-            os.environ.pop(k, None)
+            _native.set_option(k, None)
 
 
 @pytest.mark.parametrize("shape,win,maxd", [((48, 200), 35, 60), ((36, 1000), 27, 150), ((30, 2000), 35, 192)])
@@ -217,10 +218,10 @@ def test_asw_tad_volume_equals_the_in_kernel_e_tiles(shape, win, maxd, ss):
     m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, consistent=True)
     want = m.compute(tL, tR)
     try:
-        os.environ["SSAMD_ASW_EVOL"] = "0"
+        _native.set_option("SSAMD_ASW_EVOL", "0")
         assert torch.equal(m.compute(tL, tR), want)
     finally:
-        os.environ.pop("SSAMD_ASW_EVOL", None)
+        _native.set_option("SSAMD_ASW_EVOL", None)
 
 
 @pytest.mark.parametrize("win,maxd,mind,consistent", [(35, 16, 0, False), (35, 16, 0, True), (21, 7, 0, True), (9, 3, 0, False),
@@ -248,12 +249,12 @@ def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consisten
         _native.check(_native.lib().ssamd_asw_costs(L.ctypes.data, R.ctypes.data, H, W, win, maxd, mind, 6.0, 17.5, c.ctypes.data, -1))
         return m.compute(L, R), c
     try:
-        os.environ["SSAMD_ASW_WAVE"] = "0"
+        _native.set_option("SSAMD_ASW_WAVE", "0")
         want = [run(L, R) for L, R in pairs]
-        os.environ["SSAMD_ASW_WAVE"] = "1"
+        _native.set_option("SSAMD_ASW_WAVE", "1")
         ran = 0
         for rx in ("8", "4"):
-            os.environ["SSAMD_ASW_WAVE_RX"] = rx
+            _native.set_option("SSAMD_ASW_WAVE_RX", rx)
             if _native.asw_kernel_form(128, 96, win, maxd, mind)["wave_kernel"] != int(rx):
                 continue                                      # this tile does not fit LDS for the window / range
             ran += 1
@@ -264,7 +265,7 @@ def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consisten
         assert ran >= 1
     finally:
         for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX"):
-            os.environ.pop(k, None)
+            _native.set_option(k, None)
 
 
 @pytest.mark.parametrize("maxd,win", [(7, 35), (16, 35), (39, 21)])
@@ -277,17 +278,17 @@ def test_asw_wave_kernel_full_width_rows(maxd, win, ss):
     tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
     m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, consistent=True)
     try:
-        os.environ["SSAMD_ASW_WAVE"] = "0"
+        _native.set_option("SSAMD_ASW_WAVE", "0")
         want = m.compute(tL, tR)
-        os.environ["SSAMD_ASW_WAVE"] = "1"
+        _native.set_option("SSAMD_ASW_WAVE", "1")
         for rx, wg in (("8", "1"), ("4", "1"), ("8", "4"), ("4", "2")):
-            os.environ["SSAMD_ASW_WAVE_RX"], os.environ["SSAMD_ASW_WAVE_WG"] = rx, wg
+            _native.set_option("SSAMD_ASW_WAVE_RX", rx); _native.set_option("SSAMD_ASW_WAVE_WG", wg)
             assert torch.equal(m.compute(tL, tR), want), (rx, wg)
-        os.environ["SSAMD_ASW_WAVE_UNROLL"] = "0"
+        _native.set_option("SSAMD_ASW_WAVE_UNROLL", "0")
         assert torch.equal(m.compute(tL, tR), want)
     finally:
         for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL"):
-            os.environ.pop(k, None)
+            _native.set_option(k, None)
 
 
 def test_asw_wave_kernel_strips_and_alternate_rows(ss, golden_inputs):
@@ -300,12 +301,12 @@ def test_asw_wave_kernel_strips_and_alternate_rows(ss, golden_inputs):
     m = ss.passive.StereoASW(winSize=13, maxDisparity=16, consistent=True)
     alt = ss.passive.StereoASW(winSize=13, maxDisparity=16, alternate=True)
     try:
-        os.environ["SSAMD_ASW_WAVE"] = "0"
+        _native.set_option("SSAMD_ASW_WAVE", "0")
         want, want_alt = m.compute(tL, tR), alt.compute(tL, tR)
         want_strip = m._compute_device(tL[20:70].contiguous(), tR[20:70].contiguous(), out_row0=6, out_rows=38)
-        os.environ["SSAMD_ASW_WAVE"] = "1"
+        _native.set_option("SSAMD_ASW_WAVE", "1")
         for rx in ("8", "4"):
-            os.environ["SSAMD_ASW_WAVE_RX"] = rx
+            _native.set_option("SSAMD_ASW_WAVE_RX", rx)
             assert _native.asw_kernel_form(128, 96, 13, 16, 0)["wave_kernel"] == int(rx)
             assert torch.equal(m.compute(tL, tR), want)
             assert torch.equal(alt.compute(tL, tR), want_alt)
@@ -314,7 +315,7 @@ def test_asw_wave_kernel_strips_and_alternate_rows(ss, golden_inputs):
             assert torch.equal(got_strip, want[26:64])
     finally:
         for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX"):
-            os.environ.pop(k, None)
+            _native.set_option(k, None)
 
 
 @pytest.mark.parametrize("H,W,maxd,shift", [(1080, 1920, 192, 150), (2160, 4096, 256, 233)])
@@ -366,11 +367,11 @@ def test_autotune_changes_the_geometry_never_the_map(ss, golden_inputs):
     from oracle import oracle
     for p, g1, g2 in zip(cases, got_first, got_again):
         assert np.array_equal(g1, g2)
-    os.environ["SSAMD_ASW_GEOM"] = "3,5,8"           # an unrelated forced geometry computes the same maps
+    _native.set_option("SSAMD_ASW_GEOM", "3,5,8")           # an unrelated forced geometry computes the same maps
     try:
         forced = [ss.passive.StereoASW(**p).compute(a2, b2) for p in cases]
     finally:
-        del os.environ["SSAMD_ASW_GEOM"]
+        _native.set_option("SSAMD_ASW_GEOM", None)
     for g1, f in zip(got_first, forced):
         assert np.array_equal(g1, f)
     assert all(w.shape == (96, 128) for w in want)

@@ -3,6 +3,7 @@ passive.py:43-46, without code -- so there is no reference output and this mode 
 own CPU restatement built from the reference-exact pieces, oracle.asw_alternate, and by its properties)."""
 import numpy as np
 import pytest
+from simplestereo_amd import _native      # noqa: E402  (tuning options: _native.set_option)
 
 pytestmark = pytest.mark.gpu
 
@@ -111,11 +112,11 @@ def test_alternate_full_queue_falls_back_to_in_place_evaluation(ss, golden_input
     m = ss.passive.StereoASW(winSize=15, maxDisparity=16, alternate=True)
     want = m.compute(a, b)
     for cap in ("1", "37", "300"):
-        os.environ["SSAMD_ALT_QUEUE_CAP"] = cap
+        _native.set_option("SSAMD_ALT_QUEUE_CAP", cap)
         try:
             got = m.compute(a, b)
         finally:
-            del os.environ["SSAMD_ALT_QUEUE_CAP"]
+            _native.set_option("SSAMD_ALT_QUEUE_CAP", None)
         assert np.array_equal(got, want), cap
 
 
@@ -165,11 +166,11 @@ def test_alternate_with_several_disparity_chunks_goes_through_the_key_path(ss, g
     a, b = golden_inputs("synth_96x128")
     m = ss.passive.StereoASW(winSize=21, maxDisparity=39, alternate=True)
     want = m.compute(a, b)
-    os.environ["SSAMD_ASW_GEOM"] = "6,5,8"          # Dc = 20: two chunks for 40 disparities, chunked tap staging
+    _native.set_option("SSAMD_ASW_GEOM", "6,5,8")          # Dc = 20: two chunks for 40 disparities, chunked tap staging
     try:
         got = m.compute(a, b)
     finally:
-        del os.environ["SSAMD_ASW_GEOM"]
+        _native.set_option("SSAMD_ASW_GEOM", None)
     assert np.array_equal(got, want)
 
 

@@ -7,6 +7,7 @@ import os
 
 import numpy as np
 import pytest
+from simplestereo_amd import _native      # noqa: E402  (tuning options: _native.set_option)
 
 pytestmark = pytest.mark.gpu
 
@@ -121,12 +122,12 @@ def test_gsw_forced_geometries_and_strip_heights_agree(geom, ss, golden_cases, g
     m = ss.passive.StereoGSW(winSize=11, maxDisparity=24, minDisparity=0)
     base = m.compute(a, b)
     odd = m.compute(np.ascontiguousarray(a[:37]), np.ascontiguousarray(b[:37]))
-    os.environ["SSAMD_GSW_GEOM"] = geom
+    _native.set_option("SSAMD_GSW_GEOM", geom)
     try:
         got = m.compute(a, b)
         got_odd = m.compute(np.ascontiguousarray(a[:37]), np.ascontiguousarray(b[:37]))
     finally:
-        del os.environ["SSAMD_GSW_GEOM"]
+        _native.set_option("SSAMD_GSW_GEOM", None)
     assert np.array_equal(got, base)
     assert np.array_equal(got_odd, odd)
     assert np.array_equal(got, maps["G6d"])     # G6d = these parameters on this pair, from the reference

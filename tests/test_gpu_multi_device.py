@@ -8,15 +8,16 @@ import threading
 
 import numpy as np
 import pytest
+from simplestereo_amd import _native      # noqa: E402  (tuning options: _native.set_option)
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture()
 def allow_repeat():
-    os.environ["SSAMD_MULTI_ALLOW_REPEAT"] = "1"
+    _native.set_option("SSAMD_MULTI_ALLOW_REPEAT", "1")
     yield
-    os.environ.pop("SSAMD_MULTI_ALLOW_REPEAT", None)
+    _native.set_option("SSAMD_MULTI_ALLOW_REPEAT", None)
 
 
 def _devices(n):

@@ -21,7 +21,6 @@ HBM_PEAK = 8.0e12
 def measure(sizes=((1080, 1920), (2160, 4096))):
     lib = _native.lib()
     res = {}
-    was = os.environ.get("SSAMD_ASW_WAVE")
     for H, W in sizes:
         rng = np.random.default_rng(0)
         img = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda()
@@ -43,7 +42,7 @@ def measure(sizes=((1080, 1920), (2160, 4096))):
             _native.check(lib.ssamd_reproject_device(disp.data_ptr(), H, W, Q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), pts.data_ptr(), stream))
         m = ss.passive.StereoASW(winSize=5, maxDisparity=3)
 
-        os.environ["SSAMD_ASW_WAVE"] = "0"        # round-1 kernel for this tiny range: the K_LAB slot then holds the two record launches only
+        _native.set_option("SSAMD_ASW_WAVE", "0")        # round-1 kernel for this tiny range: the K_LAB slot then holds the two record launches only
 
         def lab():
             m.compute(img, img)
@@ -66,10 +65,7 @@ def measure(sizes=((1080, 1920), (2160, 4096))):
             gbs = bpp * H * W / (per * 1e-3) / 1e9
             res["%s %dx%d" % (name, W, H)] = {"ms": round(per, 4), "algorithmic_bytes_per_pixel": bpp, "GB/s": round(gbs, 1),
                                              "frac_of_8TB/s": round(gbs * 1e9 / HBM_PEAK, 3)}
-    if was is None:
-        os.environ.pop("SSAMD_ASW_WAVE", None)
-    else:
-        os.environ["SSAMD_ASW_WAVE"] = was
+    _native.set_option("SSAMD_ASW_WAVE", None)
     return res
 
 

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Build container: phase-ablation / experiment builds of libssamd (never shipped as the product):
-#   tools/build_variants.sh name1:-DFLAG1,-DFLAG2 name2:-DFLAG ...   -> simplestereo_amd/_exp/libssamd_<name>.so
+#   tools/build_variants.sh name1:-DFLAG1,-DFLAG2 name2:-DFLAG ...   -> tools/_exp/libssamd_<name>.so
 # Select one at run time with SSAMD_LIB=<path>.  (*.so files are git-ignored but travel to the GPU box.)
 cd "$(dirname "$0")/.." || exit 1
-mkdir -p simplestereo_amd/_exp
+mkdir -p tools/_exp
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fno-slp-vectorize ${flags//,/ } \
-    -o simplestereo_amd/_exp/libssamd_$name.so simplestereo_amd/csrc/ssamd_api.hip &
+    -o tools/_exp/libssamd_$name.so simplestereo_amd/csrc/ssamd_api.hip &
 done
 wait
-ls -la simplestereo_amd/_exp/
+ls -la tools/_exp/

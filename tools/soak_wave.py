@@ -43,21 +43,22 @@ while time.time() < t_end:
         _native.check(lib.ssamd_asw_costs(L.ctypes.data, R.ctypes.data, H, W, win, maxd, mind, m.gammaC, m.gammaP, c.ctypes.data, -1))
         return c
     try:
-        os.environ["SSAMD_ASW_WAVE"] = "0"
+        _native.set_option("SSAMD_ASW_WAVE", "0")
         want = m.compute(tL, tR)
         want_c = costs() if with_costs else None
-        os.environ["SSAMD_ASW_WAVE"] = "1"
+        _native.set_option("SSAMD_ASW_WAVE", "1")
         rx = str(rng.choice([8, 4]))
-        os.environ["SSAMD_ASW_WAVE_RX"] = rx
-        os.environ["SSAMD_ASW_WAVE_WG"] = str(rng.integers(1, 5))
-        os.environ["SSAMD_ASW_WAVE_UNROLL"] = str(rng.integers(0, 2))
+        _native.set_option("SSAMD_ASW_WAVE_RX", rx)
+        wg_, unroll_ = str(rng.integers(1, 5)), str(rng.integers(0, 2))
+        _native.set_option("SSAMD_ASW_WAVE_WG", wg_)
+        _native.set_option("SSAMD_ASW_WAVE_UNROLL", unroll_)
         if _native.asw_kernel_form(W, H, win, maxd, mind)["wave_kernel"] != int(rx):
             skipped += 1
             continue
         got = m.compute(tL, tR)
         if not torch.equal(got, want):
             print("MISMATCH", dict(H=H, W=W, win=win, maxd=maxd, mind=mind, cons=cons, alt=alt, rx=rx,
-                                   wg=os.environ["SSAMD_ASW_WAVE_WG"], unroll=os.environ["SSAMD_ASW_WAVE_UNROLL"],
+                                   wg=wg_, unroll=unroll_,
                                    differing=int((got != want).sum())))
             sys.exit(1)
         if with_costs and not np.array_equal(costs(), want_c, equal_nan=True):
@@ -66,5 +67,5 @@ while time.time() < t_end:
         n += 1
     finally:
         for k in HOOKS:
-            os.environ.pop(k, None)
+            _native.set_option(k, None)
 print("soak ok: %d random cases equal (%d skipped: tile does not fit LDS) in %.0f s" % (n, skipped, budget))
