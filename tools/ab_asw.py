@@ -66,6 +66,8 @@ def main():
     tmp = tempfile.mkdtemp()
     for name, env in variants:
         e = dict(os.environ); e.update(env)
+        if "SSAMD_LIB" in env:
+            e["SSAMD_EXPERIMENT"] = "1"          # the binding refuses another build of the library without it
         out = os.path.join(tmp, name + ".npz")
         p = subprocess.run([sys.executable, "-c", WORKER, json.dumps(cases), out], env=e, capture_output=True, text=True)
         if p.returncode != 0:
