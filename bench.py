@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work: started WITHOUT a launcher (no WORLD_SIZE in the environment) and with --gpus N > 1, bench.py
+re-executes itself under torch.distributed.run on a free local port -- one rank per GPU over RCCL -- and passes rank 0's
+ONE JSON line through.
+
 One "step" = one StereoASW compute of one synthetic rectified pair (BASELINE.json
 config 3: 1920x1080, maxDisparity=192, winSize=35, gammaC=5, gammaP=17.5), inputs
 already resident in HBM as uint8 BGR.  With N>1 ranks the SAME frame is cut into N
@@ -33,8 +37,15 @@ Rank 0 prints ONE JSON line.  metric = disparity MPixels/s = H*W*nD / t / 1e6
                 every thread is busy, 512 columns wide so that it stays within ~30 s; plus "hoisted": the plain-C port with the same
                 algebraic shortcut as the GPU (right weights evaluated once per pixel, not once
                 per candidate), kind "port-hoisted", timed the same way.
-  bad1_vs_cpu_ref  the second half of BASELINE's metric: % of pixels of that strip whose GPU
-                disparity differs from the CPU reference's by more than 1 level.
+  bad1_vs_cpu_ref  the second half of BASELINE's metric: % of pixels whose GPU disparity differs from the CPU
+                reference's by more than 1 level.  `percent` is taken on the committed FULL-WIDTH reference strips of
+                the headline geometry (tests/golden/wide_cases.npz W3a / W3b: 1920 x 72, D 0..192, win 35, maps
+                computed by the unmodified reference, W3b on this very frame); the figure on the narrow cpu_baseline
+                crop -- whose candidate sets are truncated by construction -- stays next to it as `crop_percent`.
+  e2e_host_arrays  the same operators called the way the reference is called: numpy arrays in, numpy array out
+                (H2D + kernels + D2H); never `value`.
+  rccl          (N > 1, or SSAMD_BENCH_FORCE_DIST=1 at N = 1) what the distributed step actually ran on: backend,
+                observed world size, per-rank device / strip rows / kernel ms / halo-exchange ms / gather ms.
 """
 import argparse
 import json
@@ -284,6 +295,122 @@ def others(dev, seed):
     return res
 
 
+def bad1_on_reference_strips(dev):
+    """GPU maps of the committed full-width reference strips (tests/golden/wide_cases.*, generated by the unmodified
+    reference through tests/golden/make_golden_wide.py) against the reference's maps: 0 s of CPU time."""
+    import numpy as np
+    import simplestereo_amd as ss
+    from simplestereo_amd.synth import make_pair
+    gdir = os.path.join(ROOT, "tests", "golden")
+    maps = np.load(os.path.join(gdir, "wide_cases.npz"))
+    meta = json.load(open(os.path.join(gdir, "wide_cases.json")))
+    cases, bad, exact, pix = {}, 0, 0, 0
+    for cid in ("W3a", "W3b"):
+        m = meta[cid]
+        H, W, maxD, seed = m["frame"]
+        L, R, _ = make_pair(H, W, maxD, seed)
+        a = np.ascontiguousarray(L[m["row0"]:m["row0"] + m["rows"]])
+        b = np.ascontiguousarray(R[m["row0"]:m["row0"] + m["rows"]])
+        p = {k: v for k, v in m["params"].items() if k != "algo"}
+        d = ss.passive.StereoASW(**p).compute(a, b)
+        diff = np.abs(d.astype(np.int32) - maps[cid].astype(np.int32))
+        cases[cid] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
+                      "pixels": int(diff.size), "consistent": bool(p["consistent"]), "recipe": m["recipe"]}
+        bad += int(np.count_nonzero(diff > 1)); exact += int(np.count_nonzero(diff == 0)); pix += int(diff.size)
+    return {"percent": 100.0 * bad / pix, "exact_percent": 100.0 * exact / pix, "pixels": pix, "cases": cases,
+            "source": "tests/golden/wide_cases.npz W3a + W3b: full-width 1920 x 72 strips of the config-3 frames (seed 0 plain, "
+                      "seed 1 = this run's frame with consistent=True), D 0..192, win 35, maps by the unmodified reference "
+                      "(_passive.cpp via oracle/_ref, tests/golden/make_golden_wide.py)"}
+
+
+def e2e_host_arrays(seed, resident_ms):
+    """The operators called like the reference is called -- numpy arrays in, a fresh numpy array out: H2D copies,
+    kernels, D2H copy, synchronous (SURVEY 8d "end-to-end per compute()").  Median of the timed calls."""
+    import numpy as np
+    import simplestereo_amd as ss
+    from simplestereo_amd.synth import make_pair
+    res = {}
+    for name, reps in (("c3_1080p_d192_w35", 5), ("default_1080p_d16_w35", 9), ("c1_tsukuba_d16_w15", 25)):
+        H, W, maxD, minD, win = CONFIGS[name]
+        L, R, _ = make_pair(H, W, maxD, seed)
+        m = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P)
+        for _ in range(2):
+            out = m.compute(L, R)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = m.compute(L, R)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        nD = maxD - minD + 1
+        res[name] = {"ms_per_step": t * 1e3, "value": H * W * nD / t / 1e6, "unit": "MPixels*disp/s",
+                     "bytes_h2d": 2 * H * W * 3, "bytes_d2h": H * W * 2, "checksum": int(out.astype(np.int64).sum()),
+                     "resident_ms_per_step": resident_ms.get(name),
+                     "overhead_vs_resident_ms": (t * 1e3 - resident_ms[name]) if resident_ms.get(name) else None}
+    return res
+
+
+class _ProbeMatcher:
+    """Launcher self-test only (--selftest-launcher, CPU + gloo, tests/test_bench_launcher_cpu.py): NOT a stereo matcher
+    and never part of a measurement -- a row-window checksum whose value at row y depends on the input rows y-pad ..
+    y+pad, so that strips + halo exchange + gather reproduce the whole-frame result only if the plumbing is right."""
+    winSize = 7
+
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None):
+        import torch
+        H = int(t1.shape[0])
+        rows = H - out_row0 if out_rows is None else int(out_rows)
+        a = t1[:, :, 0].to(torch.int64) + 2 * t2[:, :, 1].to(torch.int64)
+        c = torch.cat([torch.zeros((1, a.shape[1]), dtype=torch.int64), a.cumsum(0)], 0)
+        p = self.winSize // 2
+        y = torch.arange(out_row0, out_row0 + rows)
+        lo, hi = (y - p).clamp(min=0), (y + p + 1).clamp(max=H)
+        return ((c[hi] - c[lo]) % 32749).to(torch.int16)
+
+
+def selftest_launcher(args):
+    """ranks on CPU over gloo: StripContext.step == the whole frame; rank 0 prints ONE JSON line"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from simplestereo_amd import strips
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = 37, 50
+    rng = np.random.default_rng(5)
+    L = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+    R = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+    m = _ProbeMatcher()
+    r0, r1 = strips.strip_bounds(H, world, rank)
+    ctx = strips.StripContext(m, H, W, rank, world, "cpu")
+    for _ in range(args.warmup + args.steps):
+        out = ctx.step(L[r0:r1].contiguous(), R[r0:r1].contiguous(), gather=True)
+    ok = bool(torch.equal(out, m._compute_device(L, R)))
+    oks = [None] * world
+    dist.all_gather_object(oks, ok)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        return json.dumps({"metric": "launcher selftest (CPU, gloo, probe matcher -- not a measurement)", "ok": all(oks),
+                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": "gloo"})
+    return None
+
+
+def relaunch_under_torchrun(n):
+    """bench.py --gpus N started without a launcher: run N ranks of this very command under torch.distributed.run
+    (one process per GPU, RCCL) on a free local port; rank 0's JSON line is the only thing on stdout."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what the host driver supports (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,7 +427,14 @@ def main():
                     help="cpu_baseline sample width (centre columns); 0 = full width (minutes of CPU time at 1080p)")
     ap.add_argument("--with-alternate", action="store_true",
                     help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-array (PCIe-inclusive) timings")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU + gloo self-test of the rank launcher and the strip plumbing with a probe matcher (no GPU, "
+                         "not a measurement): tests/test_bench_launcher_cpu.py")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
 
     # stdout must carry exactly ONE JSON line.  RCCL (NCCL_DEBUG=VERSION on the GPU boxes) and other
     # native libraries write banners / warnings to C stdout, flushed at exit: keep the real stdout in a
@@ -308,6 +442,15 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    if args.selftest_launcher:
+        os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
+        result = selftest_launcher(args)
+        sys.stdout.flush()
+        if result is not None:
+            os.write(real_stdout, (result + "\n").encode())
+        return
 
     import numpy as np
     import torch
@@ -317,9 +460,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world                  # the launcher's world size is authoritative
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -345,6 +486,14 @@ def main():
                                    consistent=args.consistent)
 
     strip_ctx = strips.StripContext(matcher, H, W, rank, world, dev) if use_dist else None
+    p2p_loopback = None
+    if use_dist and world == 1:
+        # one GPU cannot host a second RCCL rank: the device-to-device point-to-point path of the halo exchange is
+        # exercised with this rank as its own peer (ncclSend / ncclRecv to self in one group), outside the timed region
+        try:
+            p2p_loopback = strips.p2p_self_probe(dev, win // 2 * W * 3)
+        except Exception as e:      # noqa: BLE001
+            p2p_loopback = "failed: " + repr(e)[:160]
 
     def step():
         if not use_dist:
@@ -363,6 +512,8 @@ def main():
     fence()
     lib.ssamd_profile_enable(1)
     lib.ssamd_profile_reset()
+    if strip_ctx is not None:
+        strip_ctx.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -370,10 +521,28 @@ def main():
     dt = time.perf_counter() - t0
     ms, launches = _native.profile_read()
     lib.ssamd_profile_enable(0)
+    rccl = None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # what every rank actually ran on, collected on rank 0
+        phases = strip_ctx.read_timing() or {}
+        strip_ctx.enable_timing(False)
+        mine = {"rank": rank, "device": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(dev),
+                "strip_rows": [r0, r1], "halo_rows": [strip_ctx.h0, strip_ctx.h1],
+                "kernel_ms": ms[_native.K_ASW_AGG] / max(1, launches[_native.K_ASW_AGG]),
+                "halo_exchange_ms": phases.get("exchange_ms"), "kernels_phase_ms": phases.get("kernels_ms"),
+                "gather_ms": phases.get("gather_ms"), "messages_sent": len(strip_ctx.sends), "messages_received": len(strip_ctx.recvs)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "flat_all_gather_into_tensor": bool(strip_ctx.flat_gather),
+                "halo_rows_per_side": strip_ctx.pad, "halo_message_bytes": strip_ctx.pad * W * 3,
+                "gather_bytes_per_rank": strip_ctx.rows_max * W * 2, "p2p_loopback_probe": p2p_loopback, "ranks": per_rank}
+        try:
+            rccl["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001
+            pass
     checksum = int(out.to(torch.int64).sum().item())
 
     if rank == 0:
@@ -422,6 +591,8 @@ def main():
                                  "note": "the roofline north_star names; not binding for this kernel"}},
             "kernels_ms_per_step": {_native.lib().ssamd_kernel_name(i).decode(): ms[i] / args.steps for i in range(_native.K_COUNT) if launches[i]},
         }
+        if rccl is not None:
+            line["rccl"] = rccl
         if world == 1 and not args.consistent and args.with_alternate:
             # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
             alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
@@ -445,7 +616,21 @@ def main():
                 line["pointwise_kernels"] = bench_pointwise.measure()
             except Exception as e:      # noqa: BLE001
                 line["pointwise_kernels"] = {"error": repr(e)[:200]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not use_dist:
+            try:
+                line["bad1_vs_cpu_ref"] = bad1_on_reference_strips(dev)
+            except Exception as e:      # noqa: BLE001
+                line["bad1_vs_cpu_ref"] = {"percent": None, "source": repr(e)[:200]}
+        if world == 1 and not use_dist and not args.no_e2e:
+            try:
+                resident = {args.config: per_step * 1e3}
+                for k in ("default_1080p_d16_w35", "c1_tsukuba_d16_w15"):
+                    if k in line.get("others", {}) and "ms_per_step" in line["others"][k]:
+                        resident[k] = line["others"][k]["ms_per_step"]
+                line["e2e_host_arrays"] = e2e_host_arrays(args.seed, resident)
+            except Exception as e:      # noqa: BLE001
+                line["e2e_host_arrays"] = {"error": repr(e)[:200]}
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1])
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
             # the CPU baseline computed (matched as a stand-alone sub-image by both)
@@ -456,9 +641,13 @@ def main():
                 gpu_map = matcher.compute(np.ascontiguousarray(L[r0s:r0s + rws, c0s:c0s + cls]),
                                           np.ascontiguousarray(R[r0s:r0s + rws, c0s:c0s + cls]))
                 diff = np.abs(gpu_map.astype(np.int32) - ref_map.astype(np.int32))
-                line["bad1_vs_cpu_ref"] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
-                                           "pixels": int(diff.size), "what": "GPU vs CPU %s map of the cpu_baseline crop (the 1920- and "
-                                           "4096-wide launch geometries are pinned by tests/test_gpu_wide_golden.py)" % cb["kind"]}
+                crop = {"crop_percent": 100.0 * float(np.mean(diff > 1)), "crop_exact_percent": 100.0 * float(np.mean(diff == 0)),
+                        "crop_pixels": int(diff.size),
+                        "crop_what": "GPU vs CPU %s map of the cpu_baseline crop, a stand-alone %d-column sub-image of a D 0..%d "
+                                     "frame: %d of its columns have truncated candidate sets whose costs saturate, so ties between "
+                                     "equal costs are frequent (see the tie breakdown); the headline `percent` is taken on "
+                                     "full-width strips" % (cb["kind"], cls, maxD, min(cls, maxD))}
+                line.setdefault("bad1_vs_cpu_ref", {}).update(crop)
                 # how many of the differing pixels are numerical ties: the raw GPU cost at the reference's disparity is
                 # within the stated raw-cost tolerance (1e-4 relative) of the GPU's own minimum -- either choice is a
                 # minimum within the arithmetic (a stand-alone 512-column crop of a D 0..192 frame has wide bands where most
@@ -474,14 +663,14 @@ def main():
                     ri = np.clip(ref_map.astype(np.int64) - minD, 0, nD - 1)
                     cg, cr_ = costs[yy, xx, gi], costs[yy, xx, ri]
                     tie = np.abs(cr_ - cg) <= 1e-4 * np.maximum(1.0, np.abs(cg))
-                    line["bad1_vs_cpu_ref"]["percent_excluding_numerical_ties"] = 100.0 * float(np.mean((diff > 1) & ~tie))
-                    line["bad1_vs_cpu_ref"]["numerical_ties_among_bad1_percent"] = 100.0 * float(np.mean((diff > 1) & tie))
+                    line["bad1_vs_cpu_ref"]["crop_percent_excluding_numerical_ties"] = 100.0 * float(np.mean((diff > 1) & ~tie))
+                    line["bad1_vs_cpu_ref"]["crop_numerical_ties_among_bad1_percent"] = 100.0 * float(np.mean((diff > 1) & tie))
                     tie6 = np.abs(cr_ - cg) <= 1e-6 * np.maximum(1.0, np.abs(cg))
-                    line["bad1_vs_cpu_ref"]["percent_excluding_ties_at_1e-6"] = 100.0 * float(np.mean((diff > 1) & ~tie6))
+                    line["bad1_vs_cpu_ref"]["crop_percent_excluding_ties_at_1e-6"] = 100.0 * float(np.mean((diff > 1) & ~tie6))
                 except Exception as e:      # noqa: BLE001
-                    line["bad1_vs_cpu_ref"]["percent_excluding_numerical_ties"] = repr(e)[:120]
+                    line["bad1_vs_cpu_ref"]["crop_percent_excluding_numerical_ties"] = repr(e)[:120]
             except Exception as e:      # noqa: BLE001
-                line["bad1_vs_cpu_ref"] = {"percent": None, "what": repr(e)[:160]}
+                line.setdefault("bad1_vs_cpu_ref", {})["crop_what"] = repr(e)[:160]
             cb.pop("map_file", None)
             line["cpu_baseline"] = cb
             if cb["value"]:

@@ -23,7 +23,7 @@ strips of the result are collected with one all_gather on equal-padded strips.
 import numpy as np
 
 __all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip", "matcher_pad",
-           "StripContext"]
+           "StripContext", "p2p_self_probe"]
 
 
 def strip_bounds(height, world_size, rank):
@@ -191,10 +191,37 @@ class StripContext:
         self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=cdev)
         self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=cdev)
         self.full = torch.empty((self.H, self.W), dtype=torch.int16, device=self.device)
+        self.backend = backend
+        self._timing = None           # list of per-step event tuples while enable_timing() is on (GPU devices only)
+
+    def enable_timing(self, on=True):
+        """Record device events around the three phases of every step (halo exchange incl. the two strip copies,
+        kernels, gather) on the current stream; read_timing() returns their totals."""
+        self._timing = [] if on and self.device.type == "cuda" else None
+
+    def read_timing(self):
+        """{'steps', 'exchange_ms', 'kernels_ms', 'gather_ms'}: per-step averages since enable_timing()"""
+        import torch
+        if not self._timing:
+            return None
+        torch.cuda.synchronize(self.device)
+        n = len(self._timing)
+        ex = sum(a.elapsed_time(b) for a, b, c, d in self._timing) / n
+        ke = sum(b.elapsed_time(c) for a, b, c, d in self._timing) / n
+        ga = sum(c.elapsed_time(d) for a, b, c, d in self._timing) / n
+        return {"steps": n, "exchange_ms": ex, "kernels_ms": ke, "gather_ms": ga}
+
+    def _mark(self):
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
 
     def step(self, own_left, own_right, gather=True):
         import torch
         import torch.distributed as dist
+        timing = self._timing is not None
+        e0 = self._mark() if timing else None
         o0, o1 = self.r0 - self.h0, self.r1 - self.h0
         self.subL[o0:o1].copy_(own_left)
         self.subR[o0:o1].copy_(own_right)
@@ -215,9 +242,17 @@ class StripContext:
                 for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
                     self.subL[lo:hi].copy_(tl)
                     self.subR[lo:hi].copy_(tr)
+        e1 = self._mark() if timing else None
         strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0, self.h0 & 1)
-        if not gather:
-            return strip
+        e2 = self._mark() if timing else None
+        out = self._gather(strip) if gather else strip
+        if timing:
+            self._timing.append((e0, e1, e2, self._mark()))
+        return out
+
+    def _gather(self, strip):
+        import torch
+        import torch.distributed as dist
         if self.world == 1 and not dist.is_initialized():
             return strip
         self.padded[:strip.shape[0]].copy_(strip)
@@ -233,6 +268,23 @@ class StripContext:
             a, b = strip_bounds(self.H, self.world, r)
             self.full[a:b].copy_(self.gathered[r, :b - a])
         return self.full
+
+
+def p2p_self_probe(device, nbytes=98304, group=None):
+    """One batched isend/irecv group in which this rank is its own peer (ncclSend / ncclRecv to self inside one
+    group): the device-to-device point-to-point path of the halo exchange, exercisable on a box with ONE GPU, where
+    no second RCCL rank can exist.  Returns True when the bytes arrive.  Needs an initialised process group."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    src = torch.arange(nbytes, dtype=torch.int64, device=device).to(torch.uint8)
+    dst = torch.zeros_like(src)
+    ops = [dist.P2POp(dist.isend, src, rank, group=group), dist.P2POp(dist.irecv, dst, rank, group=group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    return bool(torch.equal(src, dst))
 
 
 def split_rows(image, world_size):

@@ -1,0 +1,99 @@
+"""GPU tier: the RCCL branch of the strip flow, executed for real.
+
+A 1-GPU box cannot host two RCCL ranks (duplicate devices are refused), so the multi-rank message plan is covered
+over gloo (tests/test_strips_gloo.py, tests/test_gpu_strips_multiprocess.py) -- but the code that only the `nccl`
+backend takes (device-resident send / receive buffers, `all_gather_into_tensor` on the byte view of the int16 strips,
+no host staging: simplestereo_amd/strips.py StripContext.flat_gather / not staged) ran nowhere.  Here one rank
+initialises `nccl` (= RCCL on ROCm) at world size 1 and
+  * runs StripContext.step for ASW (consistent) and GSW: the result must equal compute() bit for bit;
+  * exchanges halo-sized buffers with ITSELF through one batched isend / irecv group (ncclSend / ncclRecv to self):
+    the device-to-device point-to-point path of the halo exchange;
+  * runs `bench.py --gpus 1` with SSAMD_BENCH_FORCE_DIST=1 on a small configuration and reads its `rccl` object.
+Each part runs in its own process under a timeout (an RCCL hang must not take the test session with it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[1])
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+import simplestereo_amd as ss
+from simplestereo_amd import strips
+from simplestereo_amd.synth import make_pair
+res = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+for algo, H, W, params in (("asw", 61, 200, dict(winSize=21, maxDisparity=40, consistent=True)),
+                           ("asw", 40, 300, dict(winSize=35, maxDisparity=70)),
+                           ("gsw", 45, 150, dict(winSize=11, maxDisparity=30))):
+    L, R, _ = make_pair(H, W, params["maxDisparity"], 11)
+    m = (ss.passive.StereoASW if algo == "asw" else ss.passive.StereoGSW)(**params)
+    tL, tR = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+    ctx = strips.StripContext(m, H, W, 0, 1, dev)
+    assert ctx.flat_gather and not ctx.staged and ctx.backend == "nccl"
+    ctx.enable_timing(True)
+    for _ in range(2):
+        full = ctx.step(tL, tR, gather=True)
+    t = ctx.read_timing()
+    want = m.compute(tL, tR)
+    res["%%s_%%dx%%d" %% (algo, W, H)] = {"equal": bool(torch.equal(full, want)), "timing": t}
+res["p2p_self"] = strips.p2p_self_probe(dev, 10 * 1920 * 3)
+dist.barrier(); dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+""" % ROOT
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_strip_context_over_nccl_at_world_1():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", WORKER, str(_free_port())], capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1
+    cases = [k for k in res if k[:3] in ("asw", "gsw")]
+    assert len(cases) == 3 and all(res[k]["equal"] for k in cases), res
+    assert all(res[k]["timing"]["steps"] == 2 and res[k]["timing"]["gather_ms"] >= 0 for k in cases)
+    assert res["p2p_self"] is True
+
+
+def test_bench_forced_distributed_line_at_world_1():
+    env = dict(os.environ, SSAMD_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config",
+                        "c2_480p_d64_w35", "--no-others", "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    rc = line["rccl"]
+    assert rc["backend"] == "nccl" and rc["world_size"] == 1 and rc["flat_all_gather_into_tensor"] is True
+    assert rc["p2p_loopback_probe"] is True
+    assert rc["ranks"][0]["strip_rows"] == [0, 480] and rc["ranks"][0]["kernel_ms"] > 0 and rc["ranks"][0]["gather_ms"] >= 0
+    # the same frame without the process group: identical checksum
+    env.pop("SSAMD_BENCH_FORCE_DIST")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config",
+                         "c2_480p_d64_w35", "--no-others", "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600,
+                        env=env, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    plain = json.loads([l for l in r2.stdout.splitlines() if l.strip()][-1])
+    assert plain["config"]["checksum"] == line["config"]["checksum"]
+    assert "rccl" not in plain
