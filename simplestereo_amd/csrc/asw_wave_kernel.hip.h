@@ -30,6 +30,7 @@ struct AswWaveGeom {
     int nLw, nRcw, nRw;                     // left tap columns, right centres, right tap columns of a wave's strip
     int SLw, SRw, Se;                       // floats per weight row (left / right part), bytes per e column
     int waves;                              // waves per workgroup
+    int merged, K;                          // round 3: left and right centres in ONE list of K = ceil((Txw + nRcw) / 64) build rounds
     int off_w, off_cen, off_pixL, off_pixR, off_e, off_bestL, off_bestR;     // offsets inside a wave's LDS slice
     int wave_lds;                           // bytes of LDS per wave
 };
@@ -78,7 +79,12 @@ __device__ __forceinline__ void asw_wave_order()
 #endif
 // KL, KR: build rounds (64 centres each) of the left and of the right part when the host knows them at compile time
 // (the build is then straight-line code with immediate offsets); 0: counted at run time.
-template <bool WITH_COSTS, int RX, int KL = 0, int KR = 0>
+// KM (round 3): rounds of the MERGED build -- the strip's Txw left and nRcw right centres as one list of Txw + nRcw
+// entries dealt to the lanes 64 at a time, instead of ceil(Txw / 64) + ceil(nRcw / 64) rounds with two part-filled
+// last rounds (class default D 0..16, 4-column tile: 48 + 67 centres = 2 rounds instead of 1 + 2).  The two parts
+// read different pixel rows; pixR follows pixL in LDS, so the tap address of list entry c is
+// pixL + 16 (c + j) + (c < Txw ? 0 : 32 pad): one per-lane constant per round (tapoff), set up once per wave.
+template <bool WITH_COSTS, int RX, int KL = 0, int KR = 0, int KM = 0>
 __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) void asw_aggregate_wave_kernel(const AswWaveArgs A)
 {
     constexpr int NWR = asw_nwr(RX);
@@ -196,7 +202,59 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
             *(lds_f1)(da + row1) = weight(ce0, tb0, pj1);
         }
     };
+    // merged build: per-lane tap offsets of the compile-time rounds (see the template comment)
+    uint32_t tapoff[KM > 0 ? KM : 1];
+#pragma unroll
+    for (int r = 0; r < (KM > 0 ? KM : 1); ++r) {
+        const int c = 64 * r + lane;
+        tapoff[r] = 16u * (uint32_t)c + (c < Txw ? 0u : 32u * (uint32_t)p);
+    }
+    auto build_merged = [&](uint32_t tap_b, uint32_t cen_b, uint32_t dst_b, float pj0, float pj1) {
+        asm volatile("" : "+s"(tap_b), "+s"(cen_b), "+s"(dst_b));
+        const uint32_t row1 = (uint32_t)wrow * 4;
+        if constexpr (KM > 0) {
+            const uint32_t ca = cen_b + lane16, da = dst_b + lane4, db_ = da + row1;
+            if constexpr (RX == 4 && KM <= 3) {          // registers to spare: all reads of the build in flight together
+                float4 ce[KM], ta_[KM], tb[KM];
+#pragma unroll
+                for (int r = 0; r < KM; ++r) {
+                    const uint32_t ta = tap_b + tapoff[r];
+                    ce[r] = ld4(ca + 1024 * r); ta_[r] = ld4(ta); tb[r] = ld4(ta + 16);
+                }
+#pragma unroll
+                for (int r = 0; r < KM; ++r) asm volatile("" ::"v"(ce[r].w), "v"(ta_[r].w), "v"(tb[r].w) : "memory");
+#pragma unroll
+                for (int r = 0; r < KM; ++r) {
+                    *(lds_f1)(da + 256 * r) = weight(ce[r], ta_[r], pj0);
+                    *(lds_f1)(db_ + 256 * r) = weight(ce[r], tb[r], pj1);
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                const uint32_t ta = tap_b + tapoff[r];
+                const float4 ce0 = ld4(ca + 1024 * r), ta0 = ld4(ta), tb0 = ld4(ta + 16);
+                asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w));   // keeps the reads ds_read_b128
+                *(lds_f1)(da + 256 * r) = weight(ce0, ta0, pj0);
+                *(lds_f1)(db_ + 256 * r) = weight(ce0, tb0, pj1);
+            }
+            return;
+        }
+        for (int k = 0; k < ncen; k += 64) {              // rounds counted at run time
+            const int c = k + lane;
+            const uint32_t ca = cen_b + lane16 + k * 16, ta = tap_b + lane16 + k * 16 + (c < Txw ? 0u : 32u * (uint32_t)p),
+                           da = dst_b + lane4 + k * 4;
+            const float4 ce0 = ld4(ca), ta0 = ld4(ta), tb0 = ld4(ta + 16);
+            asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w) : "memory");
+            *(lds_f1)da = weight(ce0, ta0, pj0);
+            *(lds_f1)(da + row1) = weight(ce0, tb0, pj1);
+        }
+    };
     auto build = [&](int j, float pj0, float pj1) {
+        if (KM > 0 || (KL == 0 && KR == 0 && g.merged)) {
+            build_merged(sbase + g.off_pixL + 16 * j, sbase + g.off_cen, sbase + g.off_w, pj0, pj1);
+            return;
+        }
         build_part(std::integral_constant<int, KL>{}, sbase + g.off_pixL + 16 * j, sbase + g.off_cen, sbase + g.off_w, Txw, pj0, pj1);
         build_part(std::integral_constant<int, KR>{}, sbase + g.off_pixR + 16 * j, sbase + g.off_cen + 16 * Txw, sbase + g.off_w + 4 * g.SLw,
                    nRcw, pj0, pj1);

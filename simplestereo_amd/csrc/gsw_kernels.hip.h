@@ -329,11 +329,11 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     }
 }
 
-// verification helper: gsw_sqrt_int over s = 0 .. n-1
-__global__ __launch_bounds__(256) void gsw_sqrt_probe_kernel(float *__restrict__ out, int n)
+// verification helper: gsw_sqrt_int over s = 0 .. n-1 (what = 1: the bare v_sqrt_f32, for the record of why it is not used)
+__global__ __launch_bounds__(256) void gsw_sqrt_probe_kernel(float *__restrict__ out, int n, int what)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = gsw_sqrt_int((float)i);
+    if (i < n) out[i] = what == 1 ? __builtin_amdgcn_sqrtf((float)i) : gsw_sqrt_int((float)i);
 }
 
 // BGR u8 -> packed dword per pixel (GSW works on raw BGR, _passive.cpp:740-741)

@@ -469,28 +469,38 @@ void asw_try_pipe(AswGeom &g, int win)
 // Wave-autonomous kernel for small disparity ranges (asw_wave_kernel.hip.h): geometry of one wave's strip and its
 // slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
 static constexpr int ASW_WAVE_MAX_DG = 12;
-bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
+// One candidate strip: nxg column groups, left / right centres in separate build rounds or merged into one list.
+bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool merged)
 {
     g.RX = rx;
     const int p = win / 2;
-    g.DG = (nD + ASW_RD - 1) / ASW_RD;
-    if (g.DG < 1 || g.DG > ASW_WAVE_MAX_DG) return false;
-    g.NXG = 64 / g.DG;
+    g.DG = DG;
+    g.NXG = nxg;
     g.Txw = rx * g.NXG;
     g.Dc = ASW_RD * g.DG;
     g.lanes = g.NXG * g.DG;
     g.nLw = g.Txw + 2 * p;
     g.nRcw = g.Txw + g.Dc - 1;
     g.nRw = g.nRcw + 2 * p;
-    g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
-    g.SRw = round_up(g.nRcw + 1, 64);
+    g.merged = merged ? 1 : 0;
+    if (merged) {
+        // one list of Txw + nRcw centres: the right weights follow the left ones directly, the row is padded to whole rounds
+        g.K = (g.Txw + g.nRcw + 63) / 64;
+        g.SLw = g.Txw;
+        g.SRw = round_up(g.Txw + g.nRcw + 1, 64) - g.Txw;
+    } else {
+        g.K = (g.Txw + 63) / 64 + (g.nRcw + 63) / 64;
+        g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
+        g.SRw = round_up(g.nRcw + 1, 64);
+    }
     // bytes per e column: an odd number of dwords, so that the e dwords the lanes of a wave read in one step (column
     // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
     // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
     g.Se = 4 * (g.DG | 1);
     g.waves = tune().wave_wg ? tune().wave_wg : 1;
-    // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
-    // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
+    // order matters: the build's last round reads up to 127 entries past the end of the centres and of each pixel
+    // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile -- and the merged build
+    // relies on pixR starting right behind pixL
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
     g.off_w = take((size_t)(g.SLw + g.SRw) * 4 * 2);        // two rows: tap columns j and j + 1
@@ -503,7 +513,30 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
     g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
     if ((size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8 > off) off = (size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8;
     g.wave_lds = (int)((off + 15) & ~(size_t)15);
-    return (size_t)g.wave_lds * g.waves <= 160 * 1024;
+    return g.off_pixR == g.off_pixL + g.nLw * 16 && (size_t)g.wave_lds * g.waves <= 160 * 1024;
+}
+
+// The strip of a wave: DG disparity groups x NXG <= 64 / DG column groups.  Round 3: the number of column groups and
+// whether the left and right centres are built as one list are chosen by the cost per column of a tap column's work,
+// K build rounds (~17 issue slots each: one weight per lane) + the taps (~59 slots with the 4-column tile, ~110 with
+// the 8-column one).  SSAMD_ASW_WAVE_MERGE=0 restores the round-2 form (all column groups, separate rounds).
+bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
+{
+    const int DG = (nD + ASW_RD - 1) / ASW_RD;
+    if (DG < 1 || DG > ASW_WAVE_MAX_DG) return false;
+    const int nxg_max = 64 / DG;
+    if (tune().wave_merge == 0) return asw_wave_layout_one(g, win, DG, rx, nxg_max, false);
+    const double c_round = 17.0, c_taps = rx == 8 ? 110.0 : 59.0;
+    double best = 1e30;
+    bool found = false;
+    for (int nxg = nxg_max; nxg >= std::max(1, nxg_max - 4); --nxg)
+        for (int merged = 1; merged >= 0; --merged) {
+            AswWaveGeom c;
+            if (!asw_wave_layout_one(c, win, DG, rx, nxg, merged != 0)) continue;
+            const double cost = (c.K * c_round + c_taps) / (double)c.Txw;
+            if (cost < best - 1e-9) { best = cost; g = c; found = true; }
+        }
+    return found;
 }
 
 // Which wave kernel (0: none) serves a window / disparity range.  Measured on 1080p and VGA frames, windows 11..35
@@ -892,7 +925,15 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 // build rounds known at compile time (straight-line build): the common combinations
                 const int kl = (wa.g.Txw + 63) / 64, kr = (wa.g.nRcw + 63) / 64;
                 const bool unrolled = tune().wave_unroll != 0;
-                if (unrolled && !d_costs) {
+                if (unrolled && !d_costs && wa.g.merged) {
+                    const int key = wa.g.RX * 10 + wa.g.K;                                  // merged build, K rounds
+                    if (key == 42) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 2>;        // class default D 0..16: 48 + 67 centres
+                    else if (key == 43) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 3>;
+                    else if (key == 44) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 4>;
+                    else if (key == 82) wk = asw_aggregate_wave_kernel<false, 8, 0, 0, 2>;
+                    else if (key == 83) wk = asw_aggregate_wave_kernel<false, 8, 0, 0, 3>;
+                    else if (key == 84) wk = asw_aggregate_wave_kernel<false, 8, 0, 0, 4>;
+                } else if (unrolled && !d_costs) {
                     const int key = wa.g.RX * 100 + kl * 10 + kr;
                     if (key == 822) wk = asw_aggregate_wave_kernel<false, 8, 2, 2>;         // 17..28 disparities (class default)
                     else if (key == 812) wk = asw_aggregate_wave_kernel<false, 8, 1, 2>;    // 29..48
@@ -1608,6 +1649,8 @@ int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const doubl
 
 int ssamd_debug_gsw_sqrt(int n, float *out)
 {
+    int what = 0;
+    if (n < 0) { what = 1; n = -n; }       // n < 0: the bare v_sqrt_f32 over 0 .. -n - 1 (measurement of why it is not used)
     if (!out || n <= 0 || n > GSW_TAB_SIZE) return fail(SSAMD_EINVAL, "bad argument");
     CtxLock c;
     int rc = get_ctx(-1, c);
@@ -1615,7 +1658,7 @@ int ssamd_debug_gsw_sqrt(int n, float *out)
     if ((rc = c->lab.reserve((size_t)n * 4))) return rc;
     hipStream_t s = c->stream;
     ScratchOrder order(*c, s);
-    hipLaunchKernelGGL(gsw_sqrt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (float *)c->lab.ptr, n);
+    hipLaunchKernelGGL(gsw_sqrt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (float *)c->lab.ptr, n, what);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->lab.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
