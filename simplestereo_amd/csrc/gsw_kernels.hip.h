@@ -37,6 +37,8 @@ static constexpr int GSW_TAB_SIZE = 3 * 255 * 255 + 1;
 
 struct GswGeom {
     int Tx, XG, DG, Dc, nchunks, threads, Ty, Rd;   // thread tile: Ty output rows x 4 columns x Rd disparities
+    int Hy;                         // round 3: thread groups of `threads` lanes each; group h owns output rows Ty*h .. Ty*h + Ty - 1 of the
+                                    // workgroup's strip of Ty*Hy rows, all groups share the e tile of an image row
     int nL, nT, Se, emask, Ses;     // Se = 1 << Ses: floats per e row (32-byte slots, XOR-swizzled)
     int off_w, off_e, off_ref, off_tgt, off_best;
     int lds_bytes;
@@ -66,16 +68,18 @@ __device__ __forceinline__ float gsw_sqrt_int(float s)
     return fmaf(e, h, r);
 }
 
-// A staged pixel: packed colour bytes (B | G<<8 | R<<16), their squared norm, and 1.0f / 0.0f for
-// inside / outside the image.
+// A staged pixel: packed colour bytes (B | G<<8 | R<<16), their squared norm, 1.0f / 0.0f for inside / outside the
+// image, and the cap of the colour distance towards this pixel: fMax inside the image, 0 outside -- so that
+// e = min(cap, distance) is the reference's truncated distance for an in-image target and the +0 of a skipped tap
+// otherwise (_passive.cpp:511-512, 522-530), without a multiplication by the inside flag.
 struct alignas(16) GswPix {
     uint32_t bgr, norm;
-    float inside, pad;
+    float inside, cap;
 };
 
-__device__ __forceinline__ GswPix gsw_pix(uint32_t v, float inside)
+__device__ __forceinline__ GswPix gsw_pix(uint32_t v, float inside, float cap)
 {
-    return GswPix{v, __builtin_amdgcn_udot4(v, v, 0u, false), inside, 0.f};
+    return GswPix{v, __builtin_amdgcn_udot4(v, v, 0u, false), inside, cap};
 }
 
 // |a - b|^2 over the three colour bytes = |a|^2 + |b|^2 - 2 a.b, in integers (one v_dot4_u32_u8)
@@ -170,8 +174,16 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nT = g.nT, Ses = g.Ses, emask = g.emask;
     const int nL4 = (nL + 3) & ~3, nT4 = nT + (nL4 - nL);      // staged columns, padded for the 4-column e tasks
     const int x0 = blockIdx.x * Tx;
-    const int y0 = A.row0 + blockIdx.y * TY;                     // first output row of the strip
-    const int ny = min(TY, A.row0 + A.rows - y0);                // output rows of the strip that exist
+    // Thread groups (round 3): the workgroup's strip has TY * Hy output rows; group h = tid / g.threads (whole waves)
+    // aggregates rows TY h .. TY h + TY - 1.  Staging, the support weights of all rows and the e tile -- the expensive
+    // part: a correctly rounded square root per element -- are built by ALL threads once per image row and shared, so
+    // an e tile serves win window rows of TY * Hy outputs instead of TY: (win + 3) / 4 = 3.5 rebuilds per output row
+    // with four-row strips against 6 with two-row ones.
+    const int TYS = TY * g.Hy;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / g.threads), gtid = tid - grp * g.threads;
+    const int y0 = A.row0 + blockIdx.y * TYS;                    // first output row of the strip
+    const int ny = min(TYS, A.row0 + A.rows - y0);               // output rows of the strip that exist
+    const int yg = y0 + TY * grp;                                // first output row of this thread group
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
     const bool right = A.right != 0;
@@ -182,8 +194,8 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     const int seg_lo = x0 - p;                                   // first reference tap column
     const int tgt_lo = right ? seg_lo + dlo : seg_lo - dhi;      // first target tap column
 
-    const bool active = tid < g.XG * g.DG;
-    const int xg = tid % g.XG, dg = tid / g.XG;
+    const bool active = gtid < g.XG * g.DG && TY * grp < ny;
+    const int xg = gtid % g.XG, dg = gtid / g.XG;
 
     float cost[TY][GSW_RX][RD];
 #pragma unroll
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         for (int a = 0; a < GSW_RX; ++a)
 #pragma unroll
             for (int b = 0; b < RD; ++b) cost[t][a][b] = 0.f;
-    for (int k = tid; k < TY * Tx; k += nthr) best[k] = KEY_NONE;
+    for (int k = tid; k < TYS * Tx; k += nthr) best[k] = KEY_NONE;
 
     // image rows in ascending order: every output row sees its window rows in the reference's raster order
     const int r_lo = max(0, y0 - p), r_hi = min(H - 1, y0 + ny - 1 + p);
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
             const bool isRef = k < nL4;
             const int idx = isRef ? k : k - nL4;
             const int col = (isRef ? seg_lo : tgt_lo) + idx;
-            GswPix v = gsw_pix(0u, 0.f);
-            if ((unsigned)col < (unsigned)W) v = gsw_pix((isRef ? A.ref : A.tgt)[(size_t)rr * W + col], 1.f);
+            GswPix v = gsw_pix(0u, 0.f, 0.f);
+            if ((unsigned)col < (unsigned)W) v = gsw_pix((isRef ? A.ref : A.tgt)[(size_t)rr * W + col], 1.f, A.fMax);
             (isRef ? rS : tS)[idx] = v;
         }
     };
@@ -218,23 +230,22 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         // ---- support weights of this image row for the tile's reference pixels, per output row:
         //      image row r is window row i = r - y + pad of output row y.  A thread keeps one reference
         //      column c (its centre pixel is fetched once) and walks the tap columns j.
-        bool use[TY];
+        bool use[TY];                       // this thread group's rows
 #pragma unroll
-        for (int t = 0; t < TY; ++t) use[t] = t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win;
+        for (int t = 0; t < TY; ++t) use[t] = TY * grp + t < ny && (unsigned)(r - (yg + t) + p) < (unsigned)win;
         {
             const int lanesX = min(Tx, nthr), qw = nthr / lanesX;
             const int c0 = tid % lanesX, jq = tid / lanesX;
             if (jq < qw) {
                 for (int c = c0; c < Tx; c += lanesX) {
                     const int x = x0 + c;
-#pragma unroll
-                    for (int t = 0; t < TY; ++t) {
-                        if (!use[t]) continue;
+                    for (int t = 0; t < TYS; ++t) {          // the weights of every output row of the strip
+                        if (!(t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win)) continue;
                         const int y = y0 + t, i = r - y + p;
                         float *const wT = wS + t * win * Tx + c;
                         bool reached = A.iterations > 0 && x < W;
                         if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
-                        const GswPix cpx = gsw_pix(x < W ? A.ref[(size_t)y * W + x] : 0u, 1.f);
+                        const GswPix cpx = gsw_pix(x < W ? A.ref[(size_t)y * W + x] : 0u, 1.f, 0.f);
                         // two tap columns per batch, branch-free: their table gathers are in flight together
                         for (int jb = jq; jb < win; jb += 2 * qw) {
                             float w[2];
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
 #pragma unroll
                         for (int u = 0; u < 4; ++u) ev[u] = (float)gsw_dist2(rv[u], tv[u]);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) ev[u] = fminf(A.fMax, gsw_sqrt_int(ev[u])) * tv[u].inside;
+                        for (int u = 0; u < 4; ++u) ev[u] = fminf(tv[u].cap, gsw_sqrt_int(ev[u]));
 #pragma unroll
                         for (int u = 0; u < 4; ++u) ep[u << Ses] = ev[u];
                     }
@@ -290,13 +301,14 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         if (r < r_hi) stage_row(r + 1, (r + 1) & 1);       // prefetch: its global latency sits under the taps below
 
         if (active) {
+            const float *const wG = wS + (TY * grp) * win * Tx;       // this group's weight rows
             if constexpr (TY == 1) {
-                gsw_row_taps<1, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
+                if (use[0]) gsw_row_taps<1, RD, 0, 1>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
             } else {
-                static_assert(TY == 2, "strips of 1 or 2 output rows");
-                if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
-                else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
-                else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wS, eT, win, Tx, xg, dg, Ses, emask);
+                static_assert(TY == 2, "thread tiles of 1 or 2 output rows");
+                if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
+                else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
+                else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
             }
         }
     }
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     if (active) {
 #pragma unroll
         for (int t = 0; t < TY; ++t) {
-            if (t >= ny) continue;
+            if (TY * grp + t >= ny) continue;
 #pragma unroll
             for (int xi = 0; xi < GSW_RX; ++xi) {
                 const int x = x0 + GSW_RX * xg + xi;
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
                     const bool valid = (x < W) && (d <= A.maxD) && (right ? (x + d <= W - 1) : (x - d >= 0));
                     if (valid) b = min(b, make_key(cost[t][xi][di], right ? (uint32_t)(x + d) : (uint32_t)d));
                 }
-                if (b != KEY_NONE) atomicMin(&best[t * Tx + GSW_RX * xg + xi], b);
+                if (b != KEY_NONE) atomicMin(&best[(TY * grp + t) * Tx + GSW_RX * xg + xi], b);
             }
         }
     }

@@ -61,6 +61,7 @@ struct Tuning {
     int wave_wg = 0;                  // 0 unset (one wave per workgroup), 1..4
     int wave_unroll = 1;              // 0: counted build loop
     int wave_merge = 1;               // 0: left and right centres of a strip in separate build rounds (round-2 form)
+    int asw_static = 1;               // 0: the phase-shifted kernel always reads its strides from the geometry (round-2 form)
     bool no_e2 = false, xor_only = false, multi_allow_repeat = false;
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
@@ -81,6 +82,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_WAVE_WG") t.wave_wg = v ? std::max(1, std::min(4, atoi(v))) : 0;
     else if (name == "SSAMD_ASW_WAVE_UNROLL") t.wave_unroll = num(1);
     else if (name == "SSAMD_ASW_WAVE_MERGE") t.wave_merge = num(1);
+    else if (name == "SSAMD_ASW_STATIC") t.asw_static = num(1);
     else if (name == "SSAMD_ASW_NO_E2") t.no_e2 = v != nullptr;
     else if (name == "SSAMD_ASW_XOR_ONLY") t.xor_only = v != nullptr;
     else if (name == "SSAMD_MULTI_ALLOW_REPEAT") t.multi_allow_repeat = v != nullptr;
@@ -92,7 +94,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
-                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
+                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
                                     "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE"};
 
 Tuning tuning_from_env()
@@ -529,10 +531,16 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
     const double c_round = 17.0, c_taps = rx == 8 ? 110.0 : 59.0;
     double best = 1e30;
     bool found = false;
+    // (separate rounds first: on a tie they win -- measured 1.5 % faster at D 0..32, where both forms take three rounds;
+    //  the merged form only where its straight-line instantiations exist, K <= 4: the counted loop with its per-round
+    //  select lost 7 % at D 0..3, eight rounds instead of nine)
     for (int nxg = nxg_max; nxg >= std::max(1, nxg_max - 4); --nxg)
-        for (int merged = 1; merged >= 0; --merged) {
+        for (int merged = 0; merged <= 1; ++merged) {
             AswWaveGeom c;
+            if (merged && nxg != nxg_max && tune().wave_merge == 2) continue;
             if (!asw_wave_layout_one(c, win, DG, rx, nxg, merged != 0)) continue;
+            if (merged && c.K > 4) continue;
+            if (!merged && nxg != nxg_max) continue;     // fewer column groups only pay through a saved merged round
             const double cost = (c.K * c_round + c_taps) / (double)c.Txw;
             if (cost < best - 1e-9) { best = cost; g = c; found = true; }
         }
@@ -553,7 +561,10 @@ int asw_wave_pick(int win, int nD)
     if (const int rx = tune().wave_rx) {
         return (rx == 8 || rx == 4) && asw_wave_layout(wg, win, nD, rx) ? rx : 0;
     }
-    const int first = nD <= 16 ? 4 : 8, second = 12 - first;
+    // (round 3, merged build rounds: five disparity groups -- 17..20 disparities, the class default among them -- build
+    //  48 + 67 centres in two rounds with the 4-column tile: 6.10 vs 6.27 ms at 1080p / D 0..16; from six groups on the
+    //  8-column tile wins, 6.69 vs 7.63 ms at D 0..20)
+    const int first = nD <= 20 ? 4 : 8, second = 12 - first;
     if (asw_wave_layout(wg, win, nD, first)) return first;
     return asw_wave_layout(wg, win, nD, second) ? second : 0;
 }
@@ -584,7 +595,7 @@ bool asw_geometry_forced()
 {
     const Tuning &t = tune();
     return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
-           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only;
+           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1;
 }
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
@@ -951,6 +962,13 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             const bool chunked = g.JC < win;
             if (g.pipe) {
                 auto pk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
+                // strides known at compile time for the tiles of the headline configurations (immediate offsets in the
+                // tap steps): 120 x 196 (1080p / D 0..192) and 88 x 260 (4096 x 2160 / D 0..256), 216 x 68 (D 0..64)
+                if (!d_costs && tune().asw_static != 0) {
+                    if (g.SL == 120 && g.SR == 316 && g.Se == 208) pk = asw_aggregate_pipe_kernel<false, 120, 316, 208>;
+                    else if (g.SL == 88 && g.SR == 348 && g.Se == 272) pk = asw_aggregate_pipe_kernel<false, 88, 348, 272>;
+                    else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = asw_aggregate_pipe_kernel<false, 216, 284, 80>;
+                }
                 if (int grc = grant_dyn_lds(c, (const void *)pk, g.lds_bytes)) return grc;
                 hipLaunchKernelGGL(pk, grid, block, g.lds_bytes, s, a);
                 HIP_TRY(hipGetLastError());
@@ -1059,10 +1077,10 @@ int asw_alternate_rows(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int 
 }
 
 // ------------------------------------------------------------ GSW
-bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
+bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int Hy = 1)
 {
     const int p = win / 2;
-    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = Ty == 2 ? 4 : 8;
+    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = Ty == 2 ? 4 : 8; g.Hy = Hy;
     g.Tx = GSW_RX * XG; g.Dc = g.Rd * DG;
     g.threads = round_up(XG * DG, 64);
     g.nL = g.Tx + 2 * p;
@@ -1075,14 +1093,14 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
     g.emask = std::min(P, 32) - 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    g.off_w = take((size_t)Ty * win * g.Tx * 4);
+    g.off_w = take((size_t)Ty * Hy * win * g.Tx * 4);
     const int nL4 = round_up(g.nL, 4);                 // the e tasks cover 4 columns
     g.off_e = take((size_t)nL4 * g.Se * 4);
     g.off_ref = take((size_t)nL4 * 16 * 2);            // pixel staging is double-buffered (prefetch of the next image row)
     g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16 * 2);
-    g.off_best = take((size_t)Ty * g.Tx * 8);
+    g.off_best = take((size_t)Ty * Hy * g.Tx * 8);
     g.lds_bytes = (int)off;
-    return off <= limit;
+    return off <= limit && g.threads * Hy <= GSW_MAX_THREADS;
 }
 
 // Launch geometry of the GSW kernel: strip height Ty, XG x DG thread grid.  Relative cost model of one
@@ -1110,9 +1128,9 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
 {
     if (!tune().gsw_geom.empty()) {                             // experiment hook: "XG,DG,Ty"
         const char *const env = tune().gsw_geom.c_str();
-        int XG = 0, DG = 0, Ty = 1;
-        if (sscanf(env, "%d,%d,%d", &XG, &DG, &Ty) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) &&
-            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024)) {
+        int XG = 0, DG = 0, Ty = 1, Hy = 1;                       // "XG,DG[,Ty[,Hy]]"
+        if (sscanf(env, "%d,%d,%d,%d", &XG, &DG, &Ty, &Hy) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) && Hy >= 1 && Hy <= 8 &&
+            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024, Hy)) {
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
             return SSAMD_OK;
         }
@@ -1130,25 +1148,28 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
             if (DG > 64) continue;
             if ((nD + DG * Rd - 1) / (DG * Rd) != nch) continue;
             const int xg_cap = std::min(GSW_MAX_THREADS / DG, (W + GSW_RX - 1) / GSW_RX);
+            // Hy thread groups share the e tile and the staged pixels of an image row (round 3): strips of Ty * Hy rows
+            for (int Hy = 1; Hy <= (Ty == 2 ? 4 : 1) && Ty * Hy <= std::max(rows, 1) + Ty - 1; Hy *= 2)
             for (int XG = xg_cap; XG >= 1; --XG) {
                 GswGeom g;
-                if (!gsw_layout(g, win, XG, DG, Ty, 160 * 1024)) continue;
+                if (!gsw_layout(g, win, XG, DG, Ty, 160 * 1024, Hy)) continue;
                 g.nchunks = nch;
-                const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
+                const int tot = g.threads * Hy, TyS = Ty * Hy;
+                const int waves = tot / 64, per_simd = (waves + 3) / 4;
                 const int k = std::min({4 / per_simd, (160 * 1024) / g.lds_bytes, 8});   // <= 128 VGPRs: 4 waves per SIMD
                 if (k < 1) continue;
-                const double M = (double)win * GSW_RX * Rd * c_tap;
-                const double Bw = (double)((g.Tx * win + g.threads - 1) / g.threads) * c_w;
-                const double Be = (double)((g.nL * g.Dc + g.threads - 1) / g.threads) * c_e;
-                const double strip = (double)(win + Ty - 1) * Be + (double)Ty * win * (M + Bw);
+                const double M = (double)win * GSW_RX * Rd * c_tap;                       // a thread aggregates its group's Ty rows only
+                const double Bw = (double)((g.Tx * win + tot - 1) / tot) * c_w;           // weights and e tiles are built by all threads
+                const double Be = (double)((g.nL * g.Dc + tot - 1) / tot) * c_e;
+                const double strip = (double)(win + TyS - 1) * Be + (double)TyS * win * Bw + (double)Ty * win * M;
                 const double eff = (double)Ty * win * M / strip;
                 const double d_util = (double)nD / ((double)nch * g.Dc);
-                const int xt = (W + g.Tx - 1) / g.Tx, yt = (std::max(rows, 1) + Ty - 1) / Ty;
+                const int xt = (W + g.Tx - 1) / g.Tx, yt = (std::max(rows, 1) + TyS - 1) / TyS;
                 const double x_util = (double)W / ((double)xt * g.Tx);
-                const double y_util = (double)std::max(rows, 1) / ((double)yt * Ty);
+                const double y_util = (double)std::max(rows, 1) / ((double)yt * TyS);
                 const double nwg = (double)xt * yt * nch, slots = 256.0 * k;
                 const double tail = nwg / (std::ceil(nwg / slots) * slots);
-                const double score = (double)k * XG * DG * eff * d_util * x_util * y_util * tail;
+                const double score = (double)k * XG * DG * Hy * eff * d_util * x_util * y_util * tail;
                 if (score > best_score) { best_score = score; best = g; found = true; }
             }
             if (DG <= 1) break;
@@ -1221,7 +1242,8 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.tab = d_tab;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.iterations = iterations; a.fMax = fMax;
-        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + a.g.Ty - 1) / a.g.Ty, a.g.nchunks), block(a.g.threads);
+        const int TyS = a.g.Ty * a.g.Hy;
+        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + TyS - 1) / TyS, a.g.nchunks), block(a.g.threads * a.g.Hy);
         auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
         if ((rc = grant_dyn_lds(c, (const void *)kernel, a.g.lds_bytes))) return rc;
         for (int pass = 0; pass < 2; ++pass) {
@@ -1457,8 +1479,8 @@ int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int m
     if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
     GswGeom g;
     if ((rc = gsw_choose_geometry(g, width, rows, winSize, nD))) return rc;
-    out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
-    out[5] = (width + g.Tx - 1) / g.Tx; out[6] = (rows + g.Ty - 1) / g.Ty; out[7] = g.nchunks; out[8] = g.Ty;
+    out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads * g.Hy; out[4] = g.lds_bytes;
+    out[5] = (width + g.Tx - 1) / g.Tx; out[6] = (rows + g.Ty * g.Hy - 1) / (g.Ty * g.Hy); out[7] = g.nchunks; out[8] = g.Ty * g.Hy;
     return SSAMD_OK;
 }
 

@@ -239,7 +239,8 @@ def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consisten
              (np.ascontiguousarray(a[:40, :23]), np.ascontiguousarray(b[:40, :23]))]
     nD = maxd - mind + 1
     assert _native.asw_kernel_form(1920, 1080, win, maxd, mind)["wave_kernel"] in (4, 8)
-    assert _native.asw_kernel_form(1920, 1080, 35, 16, 0)["wave_kernel"] == 8          # class default range
+    assert _native.asw_kernel_form(1920, 1080, 35, 16, 0)["wave_kernel"] == 4          # class default range (round 3: merged build rounds)
+    assert _native.asw_kernel_form(1920, 1080, 35, 20, 0)["wave_kernel"] == 8
     assert _native.asw_kernel_form(1920, 1080, 35, 64, 0)["wave_kernel"] == 0
     m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, minDisparity=mind, consistent=consistent, gammaC=6.0)
 
@@ -253,18 +254,21 @@ def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consisten
         want = [run(L, R) for L, R in pairs]
         _native.set_option("SSAMD_ASW_WAVE", "1")
         ran = 0
-        for rx in ("8", "4"):
+        # both register tiles; the strip's left and right centres as one list of build rounds (round 3, merged) and in
+        # separate rounds (round-2 form)
+        for rx, merge in (("8", None), ("4", None), ("8", "0"), ("4", "0")):
             _native.set_option("SSAMD_ASW_WAVE_RX", rx)
+            _native.set_option("SSAMD_ASW_WAVE_MERGE", merge)
             if _native.asw_kernel_form(128, 96, win, maxd, mind)["wave_kernel"] != int(rx):
                 continue                                      # this tile does not fit LDS for the window / range
             ran += 1
             for (L, R), (wd, wc) in zip(pairs, want):
                 gd, gc = run(L, R)
-                assert np.array_equal(gd, wd), (rx, L.shape)
-                assert np.array_equal(gc, wc, equal_nan=True), (rx, L.shape)
-        assert ran >= 1
+                assert np.array_equal(gd, wd), (rx, merge, L.shape)
+                assert np.array_equal(gc, wc, equal_nan=True), (rx, merge, L.shape)
+        assert ran >= 2
     finally:
-        for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX"):
+        for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_MERGE"):
             _native.set_option(k, None)
 
 

@@ -90,7 +90,11 @@ def main():
             r = results[v].get(k, {})
             row += "%12.3f%4s" % (r.get("ms", float("nan")), "" if r.get("equal_first", True) else " !!")
         print(row)
-    print(json.dumps(results))
+    if "--json" in sys.argv:
+        print(json.dumps(results))
+    else:      # geometry of every variant, compactly
+        for v in results:
+            print(v, {k: (r["geom"]["tile_x"], r["geom"]["chunk_d"], r["geom"]["threads"], r["geom"]["lds_bytes"]) for k, r in results[v].items()})
 
 
 if __name__ == "__main__":
