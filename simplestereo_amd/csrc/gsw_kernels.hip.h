@@ -40,7 +40,7 @@ struct GswGeom {
     int Hy;                         // round 3: thread groups of `threads` lanes each; group h owns output rows Ty*h .. Ty*h + Ty - 1 of the
                                     // workgroup's strip of Ty*Hy rows, all groups share the e tile of an image row
     int nL, nT, Se, emask, Ses;     // Se = 1 << Ses: floats per e row (32-byte slots, XOR-swizzled)
-    int off_w, off_e, off_ref, off_tgt, off_best;
+    int off_w, off_e, off_ref, off_tgt, off_best, off_cen;
     int lds_bytes;
 };
 
@@ -74,12 +74,12 @@ __device__ __forceinline__ float gsw_sqrt_int(float s)
 // otherwise (_passive.cpp:511-512, 522-530), without a multiplication by the inside flag.
 struct alignas(16) GswPix {
     uint32_t bgr, norm;
-    float inside, cap;
+    float cap, inside;
 };
 
 __device__ __forceinline__ GswPix gsw_pix(uint32_t v, float inside, float cap)
 {
-    return GswPix{v, __builtin_amdgcn_udot4(v, v, 0u, false), inside, cap};
+    return GswPix{v, __builtin_amdgcn_udot4(v, v, 0u, false), cap, inside};
 }
 
 // |a - b|^2 over the three colour bytes = |a|^2 + |b|^2 - 2 a.b, in integers (one v_dot4_u32_u8)
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
     float *const eT = reinterpret_cast<float *>(smem + g.off_e);          // [nL][Se]
     GswPix *const refS0 = reinterpret_cast<GswPix *>(smem + g.off_ref);   // [2][nL4]: image rows alternate
     GswPix *const tgtS0 = reinterpret_cast<GswPix *>(smem + g.off_tgt);   // [2][nT4]
-    u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [TY][Tx]
+    u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [TY * Hy][Tx]
+    uint32_t *const cenS = reinterpret_cast<uint32_t *>(smem + g.off_cen); // [TY * Hy][Tx] centre pixels of the strip's outputs
 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int W = A.W, H = A.H, win = A.win, p = A.pad;
@@ -204,7 +205,11 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         for (int a = 0; a < GSW_RX; ++a)
 #pragma unroll
             for (int b = 0; b < RD; ++b) cost[t][a][b] = 0.f;
-    for (int k = tid; k < TYS * Tx; k += nthr) best[k] = KEY_NONE;
+    for (int k = tid; k < TYS * Tx; k += nthr) {
+        best[k] = KEY_NONE;
+        const int t = k / Tx, c = k - t * Tx;
+        cenS[k] = (t < ny && x0 + c < W) ? A.ref[(size_t)(y0 + t) * W + x0 + c] : 0u;      // (published by the first barrier of the row loop)
+    }
 
     // image rows in ascending order: every output row sees its window rows in the reference's raster order
     const int r_lo = max(0, y0 - p), r_hi = min(H - 1, y0 + ny - 1 + p);
@@ -233,35 +238,45 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         bool use[TY];                       // this thread group's rows
 #pragma unroll
         for (int t = 0; t < TY; ++t) use[t] = TY * grp + t < ny && (unsigned)(r - (yg + t) + p) < (unsigned)win;
+        // (SSAMD_GABLATE_*: phase-ablation builds of tools/build_variants.sh -- wrong maps by construction, never defined in the product)
+#ifdef SSAMD_GABLATE_W
+        if (r == r_lo)
+#endif
         {
+            // tasks = (output row t of the strip, tap column j) pairs of one reference column: npair = TYS * win of them,
+            // dealt to the qw threads that share a column two at a time (their table gathers are in flight together).
+            // (Round 3: the rows are part of the deal -- with narrow tiles and tall strips a thread per (column, tap
+            // column) left a third of the threads idle and half of the gathers unused.)
             const int lanesX = min(Tx, nthr), qw = nthr / lanesX;
             const int c0 = tid % lanesX, jq = tid / lanesX;
+            const int npair = TYS * win;
             if (jq < qw) {
                 for (int c = c0; c < Tx; c += lanesX) {
                     const int x = x0 + c;
-                    for (int t = 0; t < TYS; ++t) {          // the weights of every output row of the strip
-                        if (!(t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win)) continue;
-                        const int y = y0 + t, i = r - y + p;
-                        float *const wT = wS + t * win * Tx + c;
-                        bool reached = A.iterations > 0 && x < W;
-                        if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
-                        const GswPix cpx = gsw_pix(x < W ? A.ref[(size_t)y * W + x] : 0u, 1.f, 0.f);
-                        // two tap columns per batch, branch-free: their table gathers are in flight together
-                        for (int jb = jq; jb < win; jb += 2 * qw) {
-                            float w[2];
+                    for (int pb = jq; pb < npair; pb += 2 * qw) {
+                        float w[2];
+                        int dst[2];
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                const int j = min(jb + u * qw, win - 1);
-                                const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
-                                const bool centre = i == p && j == p;
-                                const bool gather = reached && !centre && px.inside != 0.f;
-                                const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
-                                w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
-                            }
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                                if (jb + u * qw < win) wT[(jb + u * qw) * Tx] = w[u];
+                        for (int u = 0; u < 2; ++u) {
+                            const int pj = min(pb + u * qw, npair - 1);
+                            int t = 0;
+                            for (int k = 1; k < TYS; ++k) t += pj >= k * win ? 1 : 0;
+                            const int j = pj - t * win;
+                            const int y = y0 + t, i = r - y + p;
+                            const bool row_used = t < ny && (unsigned)i < (unsigned)win && pb + u * qw < npair;
+                            bool reached = A.iterations > 0 && x < W;
+                            if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
+                            const GswPix cpx = gsw_pix(cenS[t * Tx + c], 1.f, 0.f);
+                            const GswPix px = refS[c + j];          // .inside: tap column x - pad + j is in the image
+                            const bool centre = i == p && j == p;
+                            const bool gather = row_used && reached && !centre && px.inside != 0.f;
+                            const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
+                            w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
+                            dst[u] = row_used ? (t * win + j) * Tx + c : -1;
                         }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (dst[u] >= 0) wS[dst[u]] = w[u];
                     }
                 }
             }
@@ -273,6 +288,9 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         //      the e writes of a wave fall into consecutive floats, the reference pixels are broadcast
         //      reads and the target pixels consecutive 16-byte reads.  (nL is padded to a multiple of 4;
         //      the padding columns hold outside-the-image pixels and are never read by the taps.)
+#ifdef SSAMD_GABLATE_E
+        if (r == r_lo)
+#endif
         {
             const int lanesD = min(Dc, nthr), q = nthr / lanesD;
             const int dd0 = tid % lanesD, mq = tid / lanesD;
@@ -280,19 +298,30 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
                 for (int dd = dd0; dd < Dc; dd += lanesD) {
                     const int tofs = right ? dd : (Dc - 1) - dd;
                     const int eofs = dd & 7, slot = dd >> 3;
-                    for (int m = mq; 4 * m < nL; m += q) {
-                        const GswPix *const rp = refS + 4 * m, *const tp = tgtS + 4 * m + tofs;
-                        float *const ep = eT + gsw_e_offset(4 * m, slot, Ses, emask) + eofs;
+                    // running pointers: per task one add each for the pixels and the e rows, and the swizzled slot
+                    // (gsw_e_offset: (ul << Ses) + ((slot ^ ((ul >> 2) & emask)) << 3) with ul = 4 m)
+                    const int pitch = 1 << Ses, rstep = 4 * q;
+                    const GswPix *rp = refS + 4 * mq, *tp = tgtS + 4 * mq + tofs;
+                    float *erow = eT + ((4 * mq) << Ses) + eofs;
+                    for (int m = mq; 4 * m < nL; m += q, rp += rstep, tp += rstep, erow += rstep << Ses) {
+                        int swz = (slot ^ (m & emask)) << 3;
+                        asm volatile("" : "+v"(swz));          // one base, the three other rows at + k * pitch (not four running pointers)
+                        float *const ep = erow + swz;
                         GswPix rv[4], tv[4];
                         float ev[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { rv[u] = rp[u]; tv[u] = tp[u]; }
 #pragma unroll
+                        for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(tv[u].inside));      // keeps the target reads ds_read_b128 (the 12-byte form is twice as slow)
+#pragma unroll
                         for (int u = 0; u < 4; ++u) ev[u] = (float)gsw_dist2(rv[u], tv[u]);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) ev[u] = fminf(tv[u].cap, gsw_sqrt_int(ev[u]));
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) ep[u << Ses] = ev[u];
+                        for (int u = 0; u < 4; ++u) {
+                            const float d = gsw_sqrt_int(ev[u]);
+                            // v_min_f32 as written: fminf() would first canonicalise the cap it has just read from LDS (one more instruction per element)
+                            asm("v_min_f32 %0, %1, %2" : "=v"(ev[u]) : "v"(tv[u].cap), "v"(d));
+                        }
+                        ep[0] = ev[0]; ep[pitch] = ev[1]; ep[2 * pitch] = ev[2]; ep[3 * pitch] = ev[3];
                     }
                 }
             }
@@ -300,6 +329,9 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         __syncthreads();
         if (r < r_hi) stage_row(r + 1, (r + 1) & 1);       // prefetch: its global latency sits under the taps below
 
+#ifdef SSAMD_GABLATE_TAPS
+        if (r == r_lo)
+#endif
         if (active) {
             const float *const wG = wS + (TY * grp) * win * Tx;       // this group's weight rows
             if constexpr (TY == 1) {

@@ -57,17 +57,23 @@ __device__ __forceinline__ void bgr_to_lab(uint32_t B, uint32_t G, uint32_t R, f
     b = (float)(200 * (fy - fz));
 }
 
-// One thread per pixel; 4 consecutive pixels share 12 contiguous bytes but a
-// 3-byte-per-lane read is still fully coalesced at the wave level (192 B/wave).
-__global__ __launch_bounds__(256) void bgr2lab_records_kernel(const uint8_t *__restrict__ bgr,
-                                                              PixRec *__restrict__ rec, long long npix)
+// One thread per pixel; 4 consecutive pixels share 12 contiguous bytes but a 3-byte-per-lane read is still fully
+// coalesced at the wave level (192 B/wave): one unaligned 4-byte read instead of three byte reads (the 4th byte is the
+// next pixel's).
+// Both images of a pair in ONE launch (round 3: a 1080p image is a 20 us kernel, two of them plus the gap between two
+// dependent launches were a third of the pre-pass; at Tsukuba size the launch is most of it).
+__global__ __launch_bounds__(256) void bgr2lab_records_pair_kernel(const uint8_t *__restrict__ bgrL, const uint8_t *__restrict__ bgrR,
+                                                                   PixRec *__restrict__ recL, PixRec *__restrict__ recR, long long npix)
 {
-    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-    for (; p < npix; p += stride) {
+    for (; q < 2 * npix; q += stride) {
+        const bool right = q >= npix;
+        const long long p = right ? q - npix : q;
+        const uint8_t *const bgr = right ? bgrR : bgrL;
         uint32_t B, G, R;
-        if (p + 1 < npix) {                 // one unaligned 4-byte read instead of three byte reads (the 4th byte is the next pixel's)
+        if (p + 1 < npix) {
             const uint32_t v = *reinterpret_cast<const u32_unaligned *>(bgr + 3 * p);
             B = v & 0xff; G = (v >> 8) & 0xff; R = (v >> 16) & 0xff;
         } else {
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void bgr2lab_records_kernel(const uint8_t *__r
         PixRec o;
         bgr_to_lab(B, G, R, o.L, o.a, o.b);
         o.bgrx = B | (G << 8) | (R << 16);
-        rec[p] = o;
+        (right ? recR : recL)[p] = o;
     }
 }
 

@@ -777,18 +777,6 @@ int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
     return SSAMD_OK;
 }
 
-int launch_lab_records(Ctx &c, const uint8_t *d_img, PixRec *rec, int W, int r0, int r1, hipStream_t s)
-{
-    const long long npix = (long long)(r1 - r0) * W;
-    if (npix <= 0) return SSAMD_OK;
-    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 8);
-    Timed t(c, s, SSAMD_K_LAB);
-    hipLaunchKernelGGL(bgr2lab_records_kernel, dim3(blocks), dim3(256), 0, s, d_img + (size_t)r0 * W * 3,
-                       rec + (size_t)r0 * W, npix);
-    HIP_TRY(hipGetLastError());
-    return SSAMD_OK;
-}
-
 int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_disp, hipStream_t s,
                     int16_t *d_raw_right = nullptr)
 {
@@ -866,8 +854,14 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         const float *d_prox = nullptr;
         if ((rc = get_prox(c, win, gammaP, s, &d_prox))) return rc;
         const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
-        if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
-        if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
+        {       // Lab records of both images, one launch
+            const long long np2 = (long long)(r1 - r0) * W;
+            const int blocks = (int)std::min<long long>((2 * np2 + 255) / 256, 256 * 8);
+            Timed t(c, s, SSAMD_K_LAB);
+            hipLaunchKernelGGL(bgr2lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3, dR + (size_t)r0 * W * 3,
+                               (PixRec *)c.recL.ptr + (size_t)r0 * W, (PixRec *)c.recR.ptr + (size_t)r0 * W, np2);
+            HIP_TRY(hipGetLastError());
+        }
 
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
         a.prox = d_prox;
@@ -1099,6 +1093,7 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int H
     g.off_ref = take((size_t)nL4 * 16 * 2);            // pixel staging is double-buffered (prefetch of the next image row)
     g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16 * 2);
     g.off_best = take((size_t)Ty * Hy * g.Tx * 8);
+    g.off_cen = take((size_t)Ty * Hy * g.Tx * 4);
     g.lds_bytes = (int)off;
     return off <= limit && g.threads * Hy <= GSW_MAX_THREADS;
 }
@@ -1148,8 +1143,11 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
             if (DG > 64) continue;
             if ((nD + DG * Rd - 1) / (DG * Rd) != nch) continue;
             const int xg_cap = std::min(GSW_MAX_THREADS / DG, (W + GSW_RX - 1) / GSW_RX);
-            // Hy thread groups share the e tile and the staged pixels of an image row (round 3): strips of Ty * Hy rows
-            for (int Hy = 1; Hy <= (Ty == 2 ? 4 : 1) && Ty * Hy <= std::max(rows, 1) + Ty - 1; Hy *= 2)
+            // Hy thread groups share the e tile and the staged pixels of an image row (round 3): strips of Ty * Hy rows.
+            // Built, bit-exact (SSAMD_GSW_GEOM="XG,DG,Ty,Hy", tests/test_gpu_gsw.py) and MEASURED at 1080p / D 0..192:
+            // 10,25,2,2 (40-column tiles, four-row strips) 9.24 ms against 9.16 ms for 20,25,2,1 -- the third fewer e
+            // elements are paid back by the narrower tile (profiles/r03_gsw_*.txt), so the search keeps Hy = 1.
+            for (int Hy = 1; Hy <= 1; Hy *= 2)
             for (int XG = xg_cap; XG >= 1; --XG) {
                 GswGeom g;
                 if (!gsw_layout(g, win, XG, DG, Ty, 160 * 1024, Hy)) continue;
@@ -1414,7 +1412,7 @@ int ssamd_device_count(void)
 
 const char *ssamd_kernel_name(int slot)
 {
-    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel + asw_tad_volume_kernel", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
+    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_pair_kernel + asw_tad_volume_kernel", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
                                                "asw finalize (wta_decode / lr_check_fill)",
                                                "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
                                                "asw_alt_fill_kernel"};

@@ -112,11 +112,12 @@ def test_gsw_integer_sqrt_is_exact_over_whole_domain(ss):
     assert np.array_equal(out, want)
 
 
-@pytest.mark.parametrize("geom", ["8,4,1", "8,4,2", "5,3,2", "16,2,1", "3,7,2"])
+@pytest.mark.parametrize("geom", ["8,4,1", "8,4,2", "5,3,2", "16,2,1", "3,7,2", "8,4,2,2", "5,3,2,4", "3,7,2,2", "6,7,2,8"])
 def test_gsw_forced_geometries_and_strip_heights_agree(geom, ss, golden_cases, golden_inputs):
-    """one- and two-row strips, and every tile shape, accumulate each output row's taps in the reference's
-    raster order: forced shapes via the SSAMD_GSW_GEOM tuning hook reproduce the reference bit for bit
-    (odd image heights leave a half-filled last strip)"""
+    """one- and two-row strips, every tile shape, and 2 / 4 / 8 thread groups sharing the e tile of an image row (strips of
+    4 / 8 / 16 output rows, "XG,DG,Ty,Hy") accumulate each output row's taps in the reference's raster order: forced
+    shapes via the SSAMD_GSW_GEOM tuning hook reproduce the reference bit for bit (odd image heights leave a
+    part-filled last strip)"""
     maps, _ = golden_cases
     a, b = golden_inputs("synth_64x96")
     m = ss.passive.StereoGSW(winSize=11, maxDisparity=24, minDisparity=0)
