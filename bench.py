@@ -215,13 +215,21 @@ def replayed_counters(config_name, k_ms):
 
 
 def time_matcher(matcher, tL, tR, slot, steps=3, warmup=1):
-    """(wall ms per step, kernel ms per launch of profile slot `slot`) of matcher.compute on resident tensors"""
+    """(wall ms per step, kernel ms per launch of profile slot `slot`) of matcher.compute on resident tensors.
+    Short calls are repeated until the timed region is at least ~30 ms long: three launches of a 0.1 ms kernel
+    measure the start of the launch queue, not the kernel (round 2 reported 0.22 ms wall for a 0.14 ms Tsukuba call;
+    300 calls in a row take 0.123 ms each, tools/call_overhead.py)."""
     import torch
     from simplestereo_amd import _native
     lib = _native.lib()
     for _ in range(warmup):
         out = matcher.compute(tL, tR)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = matcher.compute(tL, tR)
+    torch.cuda.synchronize()
+    once = time.perf_counter() - t0
+    steps = max(steps, min(300, int(0.03 / max(once, 1e-5))))
     lib.ssamd_profile_enable(1)
     lib.ssamd_profile_reset()
     t0 = time.perf_counter()
