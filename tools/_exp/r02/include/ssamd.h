@@ -1,0 +1,229 @@
+/*
+ * ssamd.h -- C ABI of libssamd.so, the MI355X (gfx950) implementation of the
+ * SimpleStereo passive-matching hot path (Adaptive / Geodesic Support-Weight
+ * stereo).  Plain pointers and sizes only: this is the drop-in boundary a
+ * maintainer of the reference would bind instead of the CPython extension
+ * `simplestereo._passive` (see INTEGRATION.md for the ctypes stub).
+ *
+ * Reference interface each entry point replaces (paths under the reference repo):
+ *
+ *   ssamd_asw          <->  _passive.computeASW   simplestereo/_passive.cpp:293-400
+ *                           called from StereoASW.compute, passive.py:88-90
+ *   ssamd_gsw          <->  _passive.computeGSW   simplestereo/_passive.cpp:703-774
+ *                           called from StereoGSW.compute, passive.py:153-156
+ *   ssamd_*_device     same operators on buffers already resident in HBM (no
+ *                      reference counterpart: the reference has no device).
+ *
+ * Conventions
+ *   - images: uint8, C-contiguous [height][width][3], channel order B,G,R
+ *     (what cv2.imread returns; _passive.cpp:333-334 assumes the same).
+ *   - disparity: int16, C-contiguous [rows][width], caller-allocated.
+ *   - every function returns 0 on success or a negative SSAMD_E* code; a
+ *     human-readable message for the calling thread is at ssamd_last_error().
+ *   - the library never keeps a caller pointer after returning.
+ *   - calls are serialised PER DEVICE by an internal mutex (ctypes releases the
+ *     GIL during the call, the reference holds it: blocking semantics are kept);
+ *     threads that target different devices run concurrently.
+ *   - an entry point leaves the calling thread's current HIP device as it found it.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with SSAMD_ENODEVICE.
+ */
+#ifndef SSAMD_H
+#define SSAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSAMD_ABI_VERSION 1
+
+#define SSAMD_OK 0
+#define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
+#define SSAMD_ENODEVICE (-2)  /* no usable HIP device                          */
+#define SSAMD_EHIP (-3)       /* a HIP runtime call failed                     */
+#define SSAMD_ENOMEM (-4)     /* device or host allocation failed              */
+#define SSAMD_ELIMIT (-5)     /* parameters exceed what the kernels support    */
+
+int ssamd_abi_version(void);
+const char *ssamd_last_error(void);
+/* number of visible HIP devices (0 if none / runtime unavailable) */
+int ssamd_device_count(void);
+
+/* ---- host-buffer operators (H2D copy, kernels, D2H copy, synchronous) ------ */
+
+/* Adaptive Support-Weight matching; argument meaning as _passive.computeASW
+ * ("O!O!iiidd|p", _passive.cpp:301).  device: HIP device ordinal, or -1 for the
+ * current device. */
+int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width,
+              int winSize, int maxDisparity, int minDisparity,
+              double gammaC, double gammaP, int consistent,
+              int16_t *disparity, int device);
+
+/* Geodesic Support-Weight matching; argument meaning as _passive.computeGSW
+ * ("O!O!iiiifii", _passive.cpp:709).  `bins` is accepted and unused, like the
+ * reference (workerGSW never reads it). */
+int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width,
+              int winSize, int maxDisparity, int minDisparity,
+              int gamma, float fMax, int iterations, int bins,
+              int16_t *disparity, int device);
+
+/* ---- the same operators over several GPUs of one process ------------------- */
+/* The frame is cut into n_devices contiguous row strips (heights differ by at most one row; empty when there are
+ * more devices than rows); strip k, with its winSize/2 halo rows taken straight from the host arrays, is uploaded to
+ * devices[k], matched there and copied back into rows of `disparity` -- one host thread per device, so copies and
+ * kernels of all devices overlap.  Rows are the reference's independent jobs (_passive.cpp:372-374) and the
+ * left-right check / occlusion filling are row-local (251-285), so the result is bit-identical to ssamd_asw /
+ * ssamd_gsw on one device.  devices: distinct non-negative HIP ordinals.  No reference counterpart (the reference
+ * has no device); SURVEY.md section 5 `devices=` extension of StereoASW / StereoGSW.compute. */
+int ssamd_asw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    double gammaC, double gammaP, int consistent,
+                    int16_t *disparity, const int *devices, int n_devices);
+int ssamd_gsw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    int gamma, float fMax, int iterations, int bins,
+                    int16_t *disparity, const int *devices, int n_devices);
+
+/* ---- device-buffer operators (asynchronous on `stream`) -------------------- */
+/* d_img1/d_img2: device pointers to a [height][width][3] sub-image (for a row
+ * strip: the strip plus its winSize/2 halo rows).  Rows [out_row0,
+ * out_row0+out_rows) of that sub-image are matched and written to d_disparity
+ * ([out_rows][width]).  Image borders are the sub-image borders, so a strip that
+ * carries its full halo reproduces the whole-image result exactly.
+ * stream: a hipStream_t (NULL = the null stream).  The caller synchronises. */
+int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                     int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity,
+                     double gammaC, double gammaP, int consistent,
+                     int16_t *d_disparity, void *stream);
+
+int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                     int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity,
+                     int gamma, float fMax, int iterations, int bins,
+                     int16_t *d_disparity, void *stream);
+
+/* ---- "alternate pixel" ASW -------------------------------------
+ * The faster variant the reference only sketches in a docstring todo (passive.py:43-46: "compute
+ * disparity map on every other pixel with the traditional algorithm, then fill the remaining
+ * pixels using left-right disparity boundaries"); opt-in, never the default.  Even image rows are
+ * matched exactly; a pixel of an odd row searches only the disparities between the results of the
+ * pixels above and below it (copied when they agree), with the exact ASW cost.  With `consistent`
+ * the even rows also get the right-referenced pass, the left-right check and the occlusion filling
+ * of ssamd_asw before the odd rows are derived from them.  Whole images only.  Same buffers and
+ * error codes as ssamd_asw / ssamd_asw_device. */
+int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                        int winSize, int maxDisparity, int minDisparity,
+                        double gammaC, double gammaP, int consistent,
+                        int16_t *disparity, int device);
+int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                               int winSize, int maxDisparity, int minDisparity,
+                               double gammaC, double gammaP, int consistent,
+                               int16_t *d_disparity, void *stream);
+
+/* The same mode on a row range of a (sub-)image (row strips of a frame cut across GPUs or processes): rows whose index
+ * in the WHOLE image is even are matched exactly, the odd ones filled from their two exact neighbours.  row_parity =
+ * parity (0 / 1) of the sub-image's row 0 in the whole image.  A range that starts or ends with an odd row needs the
+ * exact row just outside it: the sub-image must carry winSize/2 + 1 halo rows (fewer only at the borders of the whole
+ * image).  d_disparity is int16 [out_rows][width]. */
+int ssamd_asw_alternate_rows_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                                    int row_parity, int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP,
+                                    int consistent, int16_t *d_disparity, void *stream);
+
+/* ssamd_asw_multi for the alternate-rows mode: one row strip per listed GPU (halo of winSize/2 + 1 rows). */
+int ssamd_asw_alternate_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                              int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                              const int *devices, int n_devices);
+
+/* ---- the steps either side of the matchers, on device --------- */
+
+/* RectifiedStereoRig.rectifyImages (reference _rigs.py:543-567 = cv2.remap with constant
+ * border): d_dst[y][x] = bilinear(d_src, d_mapx[y][x], d_mapy[y][x]).  d_src is uint8
+ * [src_h][src_w][3]; maps are float32 [dst_h][dst_w] (cv2.initUndistortRectifyMap layout,
+ * built once per rig on the host); interpolation 0 = nearest, 1 = linear.  The maps must be 16-byte and d_dst 4-byte
+ * aligned (any device allocation is): a thread owns four consecutive output pixels. */
+int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
+                           int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream);
+
+/* RectifiedStereoRig.get3DPoints (reference _rigs.py:569-628 = cv2.reprojectImageTo3D):
+ * d_points float32 [h][w][3] from int16 disparities and the 4x4 matrix Q (16 doubles, row
+ * major, HOST memory).  h <= 65535; when w is a multiple of 4 (four pixels per thread) d_disparity must be 8-byte and
+ * d_points 16-byte aligned (any device allocation is). */
+int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const double *Q, float *d_points, void *stream);
+
+/* ---- verification / measurement helpers ------------------------------------ */
+
+/* Raw left-referenced aggregated ASW costs, float32 [height][width][nD] with
+ * nD = maxDisparity-minDisparity+1, NaN where the reference evaluates no
+ * candidate (x-d < 0).  Host buffers, synchronous.  For tolerance tests. */
+int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    double gammaC, double gammaP, float *costs, int device);
+
+/* The two raw winner-take-all results of the consistent mode BEFORE the left-right check and the occlusion
+ * filling (_passive.cpp:188 and 248-250): left_disparity[y][x] = x - dBest of the left-referenced pass,
+ * right_match[y][xr] = dBest of the right-referenced pass, i.e. the LEFT column the right pixel xr selects (0 when
+ * its candidate loop is empty).  int16 [height][width] host buffers, synchronous.  Lets a test check the argmins
+ * against the reference's fp64 costs and the finalisation kernel against a literal restatement separately. */
+int ssamd_asw_argmins(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                      int winSize, int maxDisparity, int minDisparity,
+                      double gammaC, double gammaP,
+                      int16_t *left_disparity, int16_t *right_match, int device);
+
+/* CIELab conversion used by ASW (replaces ColorConversion::ImageFromBGR2Lab,
+ * headers/colorconversion.hpp:81-86); float32 [height][width][3]. Host buffers. */
+int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device);
+
+/* The GSW kernels' exact integer square root, evaluated on the device for s = 0 .. n-1 (n <= 195076)
+ * into a HOST buffer: lets a test prove it equals (float)sqrt((double)s) over the whole domain. */
+int ssamd_debug_gsw_sqrt(int n, float *out);
+
+/* Kernel timing with HIP events recorded on the launch stream.  After
+ * ssamd_profile_enable(1) every operator call brackets its kernels with events;
+ * ssamd_profile_read() synchronises and returns accumulated milliseconds and
+ * launch counts per kernel slot since the last ssamd_profile_reset(). */
+#define SSAMD_K_LAB 0        /* bgr2lab records                                  */
+#define SSAMD_K_ASW_AGG 1    /* ASW cost aggregation + WTA keys (dominant)       */
+#define SSAMD_K_ASW_FIN 2    /* ASW key decode / LR check / occlusion fill       */
+#define SSAMD_K_GSW_AGG 3    /* GSW weights + cost aggregation + WTA keys        */
+#define SSAMD_K_GSW_FIN 4    /* GSW LR check / occlusion fill                    */
+#define SSAMD_K_REMAP 5      /* rectification remap (bilinear)                    */
+#define SSAMD_K_REPROJECT 6  /* disparity -> 3-D points                           */
+#define SSAMD_K_ASW_ALT 7    /* alternate-rows mode: bounded search on the odd rows */
+#define SSAMD_K_COUNT 8
+int ssamd_profile_enable(int on);
+int ssamd_profile_reset(void);
+int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);
+const char *ssamd_kernel_name(int slot);
+
+/* Autotuning of the ASW launch geometry.  When it applies, the first ssamd_asw* call for a problem shape (width,
+ * rows, winSize, number of disparities) times the best tile of every class of candidates on the call's own
+ * buffers -- up to ten candidates, five launches each in round-robin order, once -- and later calls reuse the
+ * fastest.  The disparity maps do not depend on the geometry.  on = 1: always; 0: never; -1 (the default, also
+ * SSAMD_AUTOTUNE=-1): only for calls of at most 3e10 window taps (3-4 ms of kernel time: VGA / 720p frames,
+ * small disparity ranges), where the trial launches cost at most ~0.2 s once and the cost model is least reliable.  The environment
+ * variable SSAMD_AUTOTUNE=1 / 0 / -1 sets the initial mode.  Returns the previous mode. */
+int ssamd_autotune(int on);
+
+/* Launch geometry chosen for an ASW problem (for DESIGN.md / bench reporting).
+ * out[0..7] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y, grid_z */
+int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
+
+/* Which form of the ASW aggregation kernel that geometry runs: out[0] = 1 for the phase-shifted kernel
+ * (asw_aggregate_pipe_kernel: lanes along the disparity groups, pre-computed TAD volume), 0 for asw_aggregate_kernel;
+ * out[1] = columns of the register tile (8 or 4); out[2] = tap columns per chunk (0: whole window rows);
+ * out[3] = 1 when waves 0-3 build before they aggregate; out[4] = 8 or 4 when asw_aggregate_wave_kernel (small disparity
+ * ranges: every wave builds the support weights of its own strip) runs with that many columns per lane, else 0.
+ * out must hold 5 ints. */
+int ssamd_asw_kernel_form(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
+
+/* Same for a GSW problem; out[0..8] = tile_x, chunk_d, n_chunks, threads, lds_bytes, grid_x, grid_y,
+ * grid_z, strip_rows (output rows per workgroup: 1 or 2) */
+int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAMD_H */

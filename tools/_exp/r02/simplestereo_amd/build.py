@@ -1,0 +1,40 @@
+"""Build libssamd.so (HIP, gfx950) in-tree.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libssamd.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize"]
+
+
+def _sources():
+    return sorted(os.path.join(_SRC, f) for f in os.listdir(_SRC) if f.endswith((".hip", ".h")))
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = _sources() + [os.path.join(os.path.dirname(_PKG), "include", "ssamd.h")]
+    return any(os.path.getmtime(s) > t for s in deps if os.path.exists(s))
+
+
+def build_native(force=False, verbose=False):
+    """Compile simplestereo_amd/csrc/*.hip into simplestereo_amd/libssamd.so."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libssamd.so cannot be built (ROCm toolchain required)")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp", os.path.join(_SRC, "ssamd_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

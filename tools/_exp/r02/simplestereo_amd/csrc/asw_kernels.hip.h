@@ -1,0 +1,587 @@
+// K1: ASW cost aggregation + winner-take-all keys, fused (gfx950).
+//
+// Replaces the reference hot loop _passive.cpp:34-100 (left-referenced) and, by
+// the symmetry of the aggregated cost, also the right-referenced loop
+// _passive.cpp:191-253:
+//     C(y, xl, xr) = sum_t wL[y,xl,t] wR[y,xr,t] TAD(L[t+xl], R[t+xr]) / sum_t wL wR
+// is ONE number used by both passes, so a single evaluation feeds two argmins
+// (left: over xr for fixed xl; right: over xl for fixed xr).
+//
+// Work decomposition
+//   workgroup  = (image row y, tile of Tx left columns, chunk of Dc disparities)
+//   thread     = register tile of RX=8 columns x RD=4 disparities, 2 fp32 accumulators
+//                (N, S' -- see below) per (x,d) pair (RX=4 instantiation for small disparity ranges)
+//   outer loop = the window rows i (tap row r = y - pad + i).  Per window row the
+//                workgroup stages the pixels it needs in LDS (prefetched one row ahead) and
+//                builds, in LDS,
+//                  wL[j][x]   left support weights  (x in tile, tap column j)
+//                  wR[j][xr]  right support weights (xr = x - d over the tile: they
+//                             do not depend on x, the reference re-evaluates them
+//                             for every (x,d), _passive.cpp:71-74)
+//                  e[u][d]    truncated absolute difference of L[r][u], R[r][u-d]
+//                             as bytes: it depends on the tap column u = x+j-pad
+//                             only, so each value serves up to `win` taps
+//   inner loop = tap columns j; per step a thread reads 8 wL + 12 wR values (five
+//                ds_read_b128, 16-byte lane stride thanks to the parity-split rows) and
+//                ONE new dword of e (the other seven rows of its window slide in
+//                registers), then does 32 taps x {v_mul, 2 v_fma} + 4 x {cvt_ubyte, sub}.
+// HBM traffic is the pixel records only (16 B/pixel/image, re-read from L2 by
+// neighbouring tiles) plus 8-byte WTA keys; everything else lives in LDS/VGPRs.
+// Measured (1080p, D 0..192, win 35): 45.6-46.4 ms, 3.5e10 VALU wave-instructions at ~83 % of the
+// plain fp32 issue rate, no scratch, LDS ~50 % busy (profiles/).
+#pragma once
+#include "common.hip.h"
+
+namespace ssamd {
+
+static constexpr int ASW_RX = 8;      // columns per thread of the default register tile (template parameter RX: 8 or 4)
+static constexpr int ASW_RD = 4;      // disparities per thread (one packed dword of e per row)
+static constexpr int ASW_WB = 4;       // support weights evaluated side by side in the build phase
+static constexpr int ASW_MAX_THREADS = 768;
+// right weights read per tap column (float4 granules): the RX + RD - 1 centres x - d of the register tile
+__host__ __device__ constexpr int asw_nwr(int rx) { return (rx + ASW_RD - 1 + 3) / 4 * 4; }
+static_assert(ASW_RD == 4 && asw_nwr(8) == 12 && asw_nwr(4) == 8, "the main loop is unrolled for 8x4 and 4x4 register tiles");
+
+struct AswGeom {
+    int Tx, XG, DG, Dc, nchunks, threads;
+    int Rx;                      // columns per thread: 8, or 4 for small disparity ranges (twice the threads per column)
+    int nL, nR, nRc, SR, Se, emask;
+    int SL, hL, hR;              // wL row stride and the half offsets of the parity-split wL / wR rows
+    int wseg, wlen;              // weight build: tap columns (of a chunk) split in wseg segments of wlen
+    int JC;                      // tap columns staged per chunk (multiple of ASW_RX); >= win: one chunk
+    int e2;                      // 1: two e tiles (rows alternate): no barrier between the last chunk of a window row and
+                                 //    the e / weight build of the next one (chunked form with >= 2 chunks only)
+    int e_bytes;                 // size of one e tile
+    int pipe;                    // 1: asw_aggregate_pipe_kernel (asw_pipe_kernel.hip.h): phase-shifted build / aggregation
+    int NC, JCmax;               //    chunks per window row (tail shorter than 8 merged into the last) and rows per weight buffer
+    int dephase;                 //    1: waves 0-3 build before they aggregate, the others after (0: all after)
+    int wave_rx;                 // 8 or 4: asw_aggregate_wave_kernel (asw_wave_kernel.hip.h) with that many columns per lane runs
+                                 //    instead (small disparity ranges); the other fields then describe the fallback geometry
+    int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
+    int lds_bytes;
+};
+
+struct AswArgs {
+    const PixRec *recL, *recR;   // [H][W] pixel records of the (sub-)image
+    const float *prox;           // [win*win] proximity weights exp(-|t|/gammaP)
+    u64 *keyL;                   // [rows][W] left-referenced WTA keys  (cost, d)
+    u64 *keyR;                   // [rows][W] right-referenced WTA keys (cost, xl) or nullptr
+    int16_t *disp;               // non-null: ONE disparity chunk and no right pass -- every pixel is decided by exactly one
+                                 //   workgroup, which writes the disparity itself (no keys, no atomics, no decode kernel)
+    const unsigned char *evol;   // phase-shifted kernel: truncated-absolute-difference volume of asw_tad_volume_kernel (or nullptr:
+                                 //   e tiles are built in the kernel), [disparity chunk][image row - erow0][evolW columns][g.Se bytes]
+    int erow0, erows, evolW;
+    float *costs;                // optional [rows][W][nD] raw cost dump
+    int H, W, win, pad, minD, maxD, row0, rows;
+    int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)
+    float kC;                    // -log2(e)/gammaC
+    AswGeom g;
+};
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Matching-cost cap of the reference (std::min(40, ...), _passive.cpp:77).
+static constexpr float ASW_TAD_CAP = 40.0f;
+
+// Each (x,d) pair accumulates TWO weighted sums over the window taps,
+//     N  = sum w * e            and      S' = sum w * (40 - e),      w = wL*wR,
+// instead of the reference's (sum w*e, sum w).  N + S' = 40 * sum w, so
+//     cost = 40 N / (N + S')     and     40 - cost = 40 S' / (N + S').
+// fp32 keeps full RELATIVE precision on whichever of N, S' is small: costs near 0
+// and costs near the truncation value 40 (where the reference's candidates differ
+// by 1e-6 and less: occlusions, textureless areas) are both resolved, which a
+// fp32 (sum w*e)/(sum w) cannot do.  The WTA key is built from whichever form is
+// accurate (asw_cost_key).
+struct AswRow {                 // one e row of the register window: e and 40-e for the thread's disparities
+    float e[ASW_RD], c[ASW_RD];
+};
+
+__device__ __forceinline__ void asw_row_unpack(AswRow &row, const uint32_t packed)
+{
+#pragma unroll
+    for (int di = 0; di < ASW_RD; ++di) {
+        const float e = (float)((packed >> (8 * di)) & 0xffu);   // v_cvt_f32_ubyteN
+        row.e[di] = e;
+        row.c[di] = ASW_TAD_CAP - e;
+    }
+}
+
+// RX*RD taps of one tap column.  ROT: window slot of the thread's first column (slots rotate
+// by one per tap column; the rotation is resolved at compile time by unrolling RX columns).
+template <int RX, int ROT>
+__device__ __forceinline__ void asw_taps(float (&accN)[RX][ASW_RD], float (&accS)[RX][ASW_RD],
+                                         const float (&wl)[RX], const float (&wr)[asw_nwr(RX)],
+                                         const AswRow (&win)[RX])
+{
+#pragma unroll
+    for (int xi = 0; xi < RX; ++xi) {
+        const AswRow &row = win[(ROT + xi) % RX];
+#pragma unroll
+        for (int di = 0; di < ASW_RD; ++di) {
+            const float w = wl[xi] * wr[xi - di + ASW_RD - 1];
+            accN[xi][di] = fmaf(w, row.e[di], accN[xi][di]);
+            accS[xi][di] = fmaf(w, row.c[di], accS[xi][di]);
+        }
+    }
+}
+
+// Order-preserving 32-bit image of the aggregated cost of one (x,d) pair, and the
+// cost itself.  cost <= 20: bits(cost); cost > 20: 0xC0000000 - bits(40 - cost), which
+// is > bits(20.0f) and decreasing in (40 - cost): a monotone map of the cost that keeps
+// the resolution of the accurate operand.
+__device__ __forceinline__ uint32_t asw_cost_key(const float n, const float s, float &cost)
+{
+    const float t40 = n + s;
+    if (n <= s) {
+        cost = ASW_TAD_CAP * n / t40;
+        return __float_as_uint(cost);
+    }
+    const float inv = ASW_TAD_CAP * s / t40;
+    cost = ASW_TAD_CAP - inv;
+    return 0xC0000000u - __float_as_uint(inv);
+}
+
+// wL / wR rows are stored with their even and odd 16-byte blocks in two halves ("parity split"):
+// element c lives at  ((c >> 2) & 1) * half + ((c >> 3) << 2) + (c & 3).  A thread reads RX = 8
+// consecutive columns = one even + one odd block, so for each ds_read_b128 the lanes of a wave
+// (consecutive column groups) are 16 bytes apart instead of 32: no 2-way bank conflicts.
+__device__ __forceinline__ int asw_split_pos(int c, int half)
+{
+    return ((c >> 2) & 1) * half + ((c >> 3) << 2) + (c & 3);
+}
+
+// e tile addressing: rows of Se bytes (Se = 4 * power of two >= DG), one dword (RD = 4 disparities)
+// per disparity group; the dword slot of group dg in row ul is XOR-swizzled with (ul / RX) so that
+// the lanes of a wave (consecutive xg, rows RX apart) read distinct banks.
+template <int RX>
+__device__ __forceinline__ int asw_e_offset(int ul, int slot, int Se, int emask)
+{
+    return ul * Se + ((slot ^ ((ul / RX) & emask)) << 2);
+}
+
+// CHUNKED: the tap columns of a window row are staged g.JC at a time (see the loop over jc below).
+// RX: columns per thread.  8 is the throughput tile (168 VGPRs, 3 waves per SIMD).  4 halves the columns and
+// the accumulators per thread: twice the threads per tile column and 4 waves per SIMD, for small disparity
+// ranges where few threads share a weight row and LDS capacity, not VGPRs, limits the resident waves.
+template <bool WITH_COSTS, bool CHUNKED, int RX = ASW_RX>
+__global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregate_kernel(const AswArgs A)
+{
+    constexpr int NWR = asw_nwr(RX);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AswGeom &g = A.g;
+    float *const wL = reinterpret_cast<float *>(smem + g.off_wL);
+    float *const wR = reinterpret_cast<float *>(smem + g.off_wR);
+    unsigned char *const eT0 = reinterpret_cast<unsigned char *>(smem + g.off_e);
+    float4 *const labL = reinterpret_cast<float4 *>(smem + g.off_labL);
+    float4 *const labR = reinterpret_cast<float4 *>(smem + g.off_labR);
+    uint32_t *const bgrL = reinterpret_cast<uint32_t *>(smem + g.off_bgrL);
+    uint32_t *const bgrR = reinterpret_cast<uint32_t *>(smem + g.off_bgrR);
+    u64 *const bestL = reinterpret_cast<u64 *>(smem + g.off_bestL);
+    u64 *const bestR = reinterpret_cast<u64 *>(smem + g.off_bestR);
+    float4 *const cenLab = reinterpret_cast<float4 *>(smem + g.off_cen);
+    float *const proxS = reinterpret_cast<float *>(smem + g.off_prox);
+
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int W = A.W, win = A.win, p = A.pad;
+    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nR = g.nR, nRc = g.nRc, SR = g.SR, Se = g.Se, emask = g.emask;
+    // XCD-aware tile order: workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a
+    // speed assumption only).  When the row has a multiple of 8 x tiles, tile slot b of every row lands on
+    // XCD b % 8; give each XCD a run of ADJACENT tiles (slots b, b+8, ... -> tiles m*(b%8) + b/8, m = tiles/8)
+    // so that the halo columns neighbouring tiles share are served by one L2 instead of two.
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int x0 = bx * Tx;
+    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int dlo = A.minD + blockIdx.z * Dc;
+    const int dhi = dlo + Dc - 1;
+    // no (x,d) pair of this tile has x-d >= 0 (left image border): nothing to aggregate; the empty candidate
+    // loop of the reference leaves dBest = 0, i.e. the output x (_passive.cpp:54,98)
+    if (min(x0 + Tx - 1, W - 1) - dlo < 0) {
+        if (A.disp)
+            for (int k = threadIdx.x; k < Tx && x0 + k < W; k += blockDim.x)
+                A.disp[(size_t)(y - A.row0) * W + x0 + k] = (int16_t)(x0 + k);
+        return;
+    }
+
+    const int segL_lo = x0 - p;        // first tap column staged from the left image
+    const int xrc_lo = x0 - dhi;       // first right-image window centre of the tile
+    const int segR_lo = xrc_lo - p;    // first tap column staged from the right image
+
+    // lanes of a wave run along x (xg fastest): their wL / wR reads are consecutive 16-byte
+    // slots (conflict-free ds_read_b128 for any lane grouping)
+
+    float accN[RX][ASW_RD], accS[RX][ASW_RD];
+#pragma unroll
+    for (int a = 0; a < RX; ++a)
+#pragma unroll
+        for (int b = 0; b < ASW_RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
+
+    for (int k = tid; k < Tx; k += nthr) bestL[k] = KEY_NONE;
+    for (int k = tid; k <= nRc; k += nthr) bestR[k] = KEY_NONE;
+
+    // window centres (row y) of the tile: left columns x0.., then right columns xrc_lo..
+    for (int c = tid; c < Tx + nRc; c += nthr) {
+        const bool isL = c < Tx;
+        const int ccol = isL ? x0 + c : xrc_lo + (c - Tx);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ccol < (unsigned)W) {
+            const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+            v = make_float4(q.L, q.a, q.b, 1.f);
+        }
+        cenLab[c] = v;
+    }
+    // e-build task walk: task t -> (ul = t % nL, dq = t / nL), advanced incrementally
+
+    const int i_lo = max(0, p - y), i_hi = min(win, A.H + p - y);
+    // stage the pixels of image row r this tile touches into staging buffer `buf`
+    // (coalesced 16 B loads; columns outside the image become zero records)
+    auto stage_row = [&](int r, int buf) {
+        int tids = threadIdx.x;          // opaque copy: keeps the staging indices from being hoisted out of the
+        asm volatile("" : "+v"(tids));   // row loop and held (or spilled) across the aggregation
+        for (int k = tids; k < win; k += nthr) proxS[buf * win + k] = A.prox[(r - (y - p)) * win + k];
+        const PixRec *const rowL = A.recL + (size_t)r * W;
+        const PixRec *const rowR = A.recR + (size_t)r * W;
+        for (int k = tids; k < nL + nR; k += nthr) {
+            const bool isL = k < nL;
+            const int idx = isL ? k : k - nL;
+            const int col = (isL ? segL_lo : segR_lo) + idx;
+            PixRec v;
+            v.L = v.a = v.b = 0.f;
+            v.bgrx = 0u;
+            if ((unsigned)col < (unsigned)W) v = (isL ? rowL : rowR)[col];
+            (isL ? labL + buf * nL : labR + buf * nR)[idx] = make_float4(v.L, v.a, v.b, 0.f);
+            (isL ? bgrL + buf * nL : bgrR + buf * nR)[idx] = v.bgrx;
+        }
+    };
+    // Tap columns are staged JC at a time when the whole window row of weights does not leave room for
+    // enough resident waves (small disparity ranges: few threads share a weight row); chunk buffers
+    // alternate so that one barrier per chunk suffices.  JC == win: a single chunk, rows used in place.
+    const int JC = CHUNKED ? g.JC : win;
+    int cb = 0;
+    for (int i = i_lo; i < i_hi; ++i) {
+        const int r = y - p + i;
+
+        // per-phase thread indices are re-derived from an opaque copy of the thread id so that
+        // they are not kept live across the aggregation loop (168-VGPR budget, no scratch spills)
+        int tidb = threadIdx.x;
+        asm volatile("" : "+v"(tidb));
+        // ---- pixels of image row r were staged into buffer (i & 1) during the previous
+        //      iteration's aggregation (prologue for the first row): global latency is hidden
+        float4 *const labLc = labL + (i & 1) * nL, *const labRc = labR + (i & 1) * nR;
+        uint32_t *const bgrLc = bgrL + (i & 1) * nL, *const bgrRc = bgrR + (i & 1) * nR;
+        if (i == i_lo) stage_row(r, i & 1);
+        // staged pixels visible; every thread is done with main(i-1).  With two e tiles the barrier is only needed
+        // for the first row: the pixels of later rows were staged before an earlier chunk barrier of the previous row,
+        // this row's e tile and first weight chunk go to the buffers the previous row's last chunk does not read,
+        // and stragglers of that chunk are waited for at this row's first chunk barrier.
+        if (!(CHUNKED && g.e2) || i == i_lo) __syncthreads();
+        unsigned char *const eT = eT0 + ((CHUNKED && g.e2) ? (i & 1) * g.e_bytes : 0);
+
+        // ---- truncated absolute differences e[ul][d] = min(40, |dB|+|dG|+|dR|) (_passive.cpp:77-79);
+        //      pixel bytes are B,G,R,0 so v_sad_u8 sums the 3 channels.  Task = (tap column ul,
+        //      pair of disparity groups = 8 disparities); consecutive lanes = consecutive ul.
+        {
+            const int nsp = (g.DG + 1) >> 1, e_q = nthr / nL, e_r = nthr - e_q * nL;
+            int sp = tidb / nL, ul = tidb - sp * nL;
+            while (sp < nsp) {
+                const uint32_t lp = bgrLc[ul];
+                const uint32_t *const rp = bgrRc + (ul + (Dc - 1) - 8 * sp);   // R[u-d] for d = dlo + 8*sp
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lo |= min(__builtin_amdgcn_sad_u8(lp, rp[-k], 0u), 40u) << (8 * k);
+                    hi |= min(__builtin_amdgcn_sad_u8(lp, rp[-4 - k], 0u), 40u) << (8 * k);
+                }
+                *reinterpret_cast<uint32_t *>(eT + asw_e_offset<RX>(ul, 2 * sp, Se, emask)) = lo;
+                if (2 * sp + 1 < g.DG) *reinterpret_cast<uint32_t *>(eT + asw_e_offset<RX>(ul, 2 * sp + 1, Se, emask)) = hi;
+                ul += e_r; sp += e_q;
+                if (ul >= nL) { ul -= nL; ++sp; }
+            }
+        }
+
+        // ---- per-row aggregation state (register window of e rows, running e pointer)
+        int tidm = threadIdx.x;
+        asm volatile("" : "+v"(tidm));
+        // a register tile contributes only if some (x,d) of it is a candidate the reference evaluates
+        // (x - d >= 0, d <= maxDisparity, x < W); waves whose lanes are all outside (left image border,
+        // padded disparities) skip the aggregation -- wave-uniform, decided once per window row
+        bool run;
+        {
+            const int xg = tidm % g.XG, dg = tidm / g.XG;
+            const bool tile_live = tidm < g.XG * g.DG && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
+                                   x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
+            run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
+        }
+        AswRow ew[RX];      // the only per-row state (besides the accumulators) that lives across the chunks' build phases
+
+        for (int jc = 0; jc < win; jc += JC) {
+            const int jend = min(win, jc + JC);
+            const int rb = CHUNKED ? cb * JC : 0;          // first buffer row of this chunk
+            // ---- support weights of window row i, tap columns [jc, jend) (_passive.cpp:47-50 and 71-74;
+            //      exp(-dist/gammaC) = exp2(dist*kC)).  Task = (window centre c, segment of the tap
+            //      columns); consecutive lanes take consecutive centres: conflict-free ds_read_b128 of the
+            //      staged pixels and coalesced LDS writes.  Branch-free: taps or centres outside the image
+            //      get weight 0 through a bit mask.
+            {
+                int tidw = threadIdx.x;
+                asm volatile("" : "+v"(tidw));
+                const float *const prow = proxS + (i & 1) * win;    // proximity weights of window row i, staged in LDS
+                const int ncen = Tx + nRc;
+                for (int t = tidw; t < ncen * g.wseg; t += nthr) {
+                    const int sgm = t / ncen, c = t - sgm * ncen;
+                    const bool isL = c < Tx;
+                    const int cc = isL ? c : c - Tx;
+                    const float4 cen = cenLab[c];                      // centre pixel (row y); .w = inside image
+                    const float4 *const seg = (isL ? labLc : labRc) + cc;
+                    const int stride = isL ? g.SL : SR;
+                    float *const wout = (isL ? wL : wR) + asw_split_pos(cc, isL ? g.hL : g.hR) + (rb - jc) * stride;
+                    const int col0 = (isL ? x0 : xrc_lo) + cc - p;
+                    const int j1 = min(jend, jc + (sgm + 1) * g.wlen);
+                    const uint32_t cmask = cen.w != 0.f ? 0xffffffffu : 0u;
+                    // batches of ASW_WB independent evaluations: all LDS reads first, then the dependent
+                    // chains (sub, fma, v_sqrt, v_exp, mul) side by side -- a single chain is ~150 cycles of
+                    // latency, and during this phase every wave of the group is in the same loop.  Whole
+                    // batches walk running pointers (staged pixels, proximity row, output column); only the
+                    // last, partial batch of a segment pays for clamped indices.
+                    int j = jc + sgm * g.wlen;
+                    const float4 *sp = seg + j;
+                    const float *pp = prow + j;
+                    float *wp = wout + j * stride;
+                    int col = col0 + j;
+                    const int stride4 = ASW_WB * stride;
+                    for (; j + ASW_WB <= j1; j += ASW_WB, sp += ASW_WB, pp += ASW_WB, wp += stride4, col += ASW_WB) {
+                        float4 tp[ASW_WB];
+                        float pr[ASW_WB], wv[ASW_WB];
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) { tp[u] = sp[u]; pr[u] = pp[u]; }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                            wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                        }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
+                            wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                        }
+                    }
+                    if (j < j1) {
+                        float4 tp[ASW_WB];
+                        float pr[ASW_WB], wv[ASW_WB];
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const int jj = min(j + u, j1 - 1);
+                            tp[u] = seg[jj];
+                            pr[u] = prow[jj];
+                        }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {
+                            const float dL = tp[u].x - cen.x, da = tp[u].y - cen.y, db = tp[u].z - cen.z;
+                            wv[u] = fmaf(db, db, fmaf(da, da, dL * dL));
+                        }
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+#pragma unroll
+                        for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
+                            const int jj = min(j + u, j1 - 1);
+                            const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
+                            wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // e tile and this chunk of wL, wR ready; every thread is done with the previous chunk
+            if (jc == 0 && i + 1 < i_hi) stage_row(r + 1, (i + 1) & 1);   // prefetch: overlaps with the aggregation below
+
+            // ---- aggregation over the tap columns of this chunk
+            if (run) {
+                // thread coordinates, e-row pointer and swizzle state are re-derived per chunk from an opaque thread
+                // id: nothing but the e window and the accumulators stays live across a weight-build phase
+                int tida = threadIdx.x;
+                asm volatile("" : "+v"(tida));
+                const int xg = tida % g.XG, dg = tida / g.XG;
+                // the next e row to load is ul0 + RX - 1 + jc (ul0 + 0 before the priming of the first chunk); the
+                // swizzled dword slot of the thread's disparity group depends on row / RX only, i.e. it changes
+                // once per RX tap columns
+                const unsigned char *erow = eT + (RX * xg + (jc == 0 ? 0 : RX - 1 + jc)) * Se;
+                int q = xg + jc / RX;
+                int slotA = (dg ^ (q & emask)) << 2;
+                if (jc == 0) {
+#pragma unroll
+                    for (int n = 0; n < RX - 1; ++n) {
+                        asw_row_unpack(ew[n], *reinterpret_cast<const uint32_t *>(erow + slotA));
+                        erow += Se;
+                    }
+                }
+                // running LDS pointers (advanced by one tap column per step) keep the address arithmetic at
+                // ~4 VALU ops per step and nothing step-specific live across the loop
+                // RX = 8: even block of the thread's columns, odd block at + hL;  RX = 4: the thread's single block
+                const float *wlp = wL + rb * g.SL + (RX == 8 ? RX / 2 * xg : (xg & 1) * g.hL + ((xg >> 1) << 2));
+                // right weights: NWR/4 consecutive 4-float blocks starting at block b0 (parity-split rows)
+                const int b0 = (RX * xg - ASW_RD * dg + Dc - ASW_RD) >> 2;
+                const float *wrp0 = wR + rb * SR + (b0 & 1) * g.hR + ((b0 >> 1) << 2);
+                const float *wrp1 = wR + rb * SR + ((b0 + 1) & 1) * g.hR + (((b0 + 1) >> 1) << 2);
+                const float *wrp2 = wR + rb * SR + (b0 & 1) * g.hR + (((b0 + 2) >> 1) << 2);
+                for (int j0 = jc; j0 < jend; j0 += RX) {
+                    const int slotB = (dg ^ ((q + 1) & emask)) << 2;
+#define SSAMD_STEP(JJ, SLOT)                                                                        \
+    if (j0 + (JJ) < jend) {                                                                         \
+        asw_row_unpack(ew[((JJ) + RX - 1) % RX], *reinterpret_cast<const uint32_t *>(erow + (SLOT))); \
+        erow += Se;                                                                                 \
+        float wl[RX], wr[NWR];                                                              \
+        {                                                                                           \
+            const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                              \
+            wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                                 \
+            if constexpr (RX == 8) {                                                                \
+                const float4 v1 = *reinterpret_cast<const float4 *>(wlp + g.hL);                   \
+                wl[RX - 4] = v1.x; wl[RX - 3] = v1.y; wl[RX - 2] = v1.z; wl[RX - 1] = v1.w;         \
+            }                                                                                       \
+            const float4 r0 = *reinterpret_cast<const float4 *>(wrp0);                             \
+            const float4 r1 = *reinterpret_cast<const float4 *>(wrp1);                             \
+            wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                                 \
+            wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                                 \
+            if constexpr (RX == 8) {                                                                \
+                const float4 r2 = *reinterpret_cast<const float4 *>(wrp2);                         \
+                wr[NWR - 4] = r2.x; wr[NWR - 3] = r2.y; wr[NWR - 2] = r2.z; wr[NWR - 1] = r2.w;     \
+            }                                                                                       \
+        }                                                                                           \
+        wlp += g.SL; wrp0 += SR; wrp1 += SR; wrp2 += SR;                                            \
+        asw_taps<RX, (JJ)>(accN, accS, wl, wr, ew);                                                 \
+    }
+                    // the row loaded at step JJ is row j + RX - 1: (row / RX) == q for JJ = 0, q + 1 afterwards
+                    SSAMD_STEP(0, slotA) SSAMD_STEP(1, slotB) SSAMD_STEP(2, slotB) SSAMD_STEP(3, slotB)
+                    if constexpr (RX == 8) {
+                        SSAMD_STEP(RX - 4, slotB) SSAMD_STEP(RX - 3, slotB) SSAMD_STEP(RX - 2, slotB) SSAMD_STEP(RX - 1, slotB)
+                    }
+#undef SSAMD_STEP
+                    slotA = slotB;
+                    ++q;
+                }
+            }
+            if (CHUNKED) cb ^= 1;
+        }
+    }
+
+    // ---- weighted average (_passive.cpp:88) and the two WTA reductions
+    int tidf = threadIdx.x;
+    asm volatile("" : "+v"(tidf));
+    if (tidf < g.XG * g.DG) {
+        const int xg = tidf % g.XG, dg = tidf / g.XG;
+        u64 diag[RX + ASW_RD - 1];
+#pragma unroll
+        for (int k = 0; k < RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;
+#pragma unroll
+        for (int xi = 0; xi < RX; ++xi) {
+            const int x = x0 + RX * xg + xi;
+            u64 bl = KEY_NONE;
+#pragma unroll
+            for (int di = 0; di < ASW_RD; ++di) {
+                const int d = dlo + ASW_RD * dg + di;
+                const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
+                if (valid) {
+                    float c;
+                    const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
+                    bl = min(bl, hi | (u64)(uint32_t)d);
+                    diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
+                    if (WITH_COSTS)
+                        A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                }
+            }
+            if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);
+        }
+        if (A.keyR) {
+            const int base = RX * xg - ASW_RD * dg + Dc - ASW_RD;
+#pragma unroll
+            for (int k = 0; k < RX + ASW_RD - 1; ++k)
+                if (diag[k] != KEY_NONE) atomicMin(&bestR[base + k], diag[k]);
+        }
+    }
+    __syncthreads();
+    const size_t orow = (size_t)(y - A.row0) * W;
+    if (A.disp) {
+        for (int k = tid; k < Tx; k += nthr) {
+            const int x = x0 + k;
+            if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
+        }
+        return;
+    }
+    for (int k = tid; k < Tx; k += nthr) {
+        const int x = x0 + k;
+        if (x < W && bestL[k] != KEY_NONE) atomicMin(&A.keyL[orow + x], bestL[k]);
+    }
+    if (A.keyR) {
+        for (int k = tid; k < nRc; k += nthr) {
+            const int xr = xrc_lo + k;
+            if ((unsigned)xr < (unsigned)W && bestR[k] != KEY_NONE) atomicMin(&A.keyR[orow + xr], bestR[k]);
+        }
+    }
+}
+
+// K2a: decode left keys (non-consistent mode).  disparity = d of the best key, or x
+// when the candidate loop was empty (dBest stays 0, _passive.cpp:54,98).
+// right_keys != 0: the keys are right-referenced (low word = best LEFT column of the right pixel, 0 when its
+// candidate loop was empty, _passive.cpp:209) -- only used by the verification dump ssamd_asw_argmins.
+__global__ __launch_bounds__(256) void wta_decode_kernel(const u64 *__restrict__ keyL, int16_t *__restrict__ disp,
+                                                         int rows, int W, int right_keys)
+{
+    const long long n = (long long)rows * W;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; idx < n; idx += stride) {
+        const u64 k = keyL[idx];
+        const int x = right_keys ? 0 : (int)(idx % W);
+        disp[idx] = (k == KEY_NONE) ? (int16_t)x : (int16_t)(uint32_t)k;
+    }
+}
+
+// K2b: left-right check + occlusion filling, one workgroup per image row
+// (_passive.cpp:250-285; GSW 661-696).  keyR low word = best left column for the
+// right pixel, 0 when its candidate loop was empty (dBest stays 0, :209).
+// A left pixel is invalidated iff some right pixel selects it while the left
+// disparity disagrees; this is order independent, unlike the reference's
+// sequential formulation.  Runs of invalid pixels take min(left,right) valid
+// neighbour, or the single valid neighbour at the image border.  A fully invalid
+// row keeps -1 (the reference reads out of bounds there).
+__global__ __launch_bounds__(256) void lr_check_fill_kernel(const u64 *__restrict__ keyL, const u64 *__restrict__ keyR,
+                                                            int16_t *__restrict__ disp, int rows, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int16_t *d = reinterpret_cast<int16_t *>(smem);
+    unsigned char *inv = reinterpret_cast<unsigned char *>(smem + (((size_t)W * 2 + 15) & ~(size_t)15));
+    const int y = blockIdx.x;
+    const u64 *kl = keyL + (size_t)y * W, *kr = keyR + (size_t)y * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const u64 k = kl[x];
+        d[x] = (k == KEY_NONE) ? (int16_t)x : (int16_t)(uint32_t)k;
+        inv[x] = 0;
+    }
+    __syncthreads();
+    for (int xr = threadIdx.x; xr < W; xr += blockDim.x) {
+        const u64 k = kr[xr];
+        const int best = (k == KEY_NONE) ? 0 : (int)(uint32_t)k;
+        if ((int)d[best] != best - xr) inv[best] = 1;
+    }
+    __syncthreads();
+    int16_t *out = disp + (size_t)y * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int16_t v = d[x];
+        if (inv[x]) {
+            int lo = x - 1, hi = x + 1;
+            while (lo >= 0 && inv[lo]) --lo;
+            while (hi < W && inv[hi]) ++hi;
+            if (lo < 0 && hi >= W) v = -1;
+            else if (lo < 0) v = d[hi];
+            else if (hi >= W) v = d[lo];
+            else v = min(d[lo], d[hi]);
+        }
+        out[x] = v;
+    }
+}
+
+}  // namespace ssamd

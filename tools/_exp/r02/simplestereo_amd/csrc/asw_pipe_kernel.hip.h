@@ -111,14 +111,9 @@ __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__res
 // (A 6-column register tile -- 48 accumulators, 128 VGPRs, FOUR waves per SIMD in 1024-thread groups, right weights
 // read as 8-byte pairs -- was built and measured in round 2: bit-identical maps, 43.6 ms against 38.2 ms for this
 // kernel on 1080p / 193 / 35.  A third more LDS traffic per tap outweighs the fourth wave; code removed.)
-// SLC, SRC, SEC (round 3): the strides of the left / right weight rows (floats) and of the e rows (bytes) as
-// compile-time constants for the launch geometries of the headline configurations (0: read from the geometry at run
-// time).  The eight steps of a trip then address their operands with immediate offsets from one pointer per array,
-// advanced once per trip: 3 address instructions per 8 steps instead of 24 (107 -> 104.4 VALU instructions per step).
-template <bool WITH_COSTS, int SLC = 0, int SRC = 0, int SEC = 0>
+template <bool WITH_COSTS>
 __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(const AswArgs A)
 {
-    constexpr bool STATIC = SLC > 0;
     constexpr int RX = ASW_RX;
     constexpr int NWR = asw_nwr(RX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -347,9 +342,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     // (SSAMD_ABLATE_*: phase-ablation builds of tools/build_variants.sh, never defined in the product)
     auto build_next = [&](int i, int c, int cb) {
         const bool more_rows = i + 1 < i_hi;
-#ifdef SSAMD_PIPE_BUILD_PRIO          // experiment (tools/build_variants.sh): the latency-bound build chains at a raised issue priority
-        __builtin_amdgcn_s_setprio(SSAMD_PIPE_BUILD_PRIO);
-#endif
 #ifndef SSAMD_ABLATE_STAGE
         if (c == 0 && more_rows) stage_row(i + 1);
 #endif
@@ -363,9 +355,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
 #ifndef SSAMD_ABLATE_E
         if (c >= 1 && more_rows && !A.evol) build_e(i + 1, (int)((long long)nE * (c - 1) / (NC - 1)), (int)((long long)nE * c / (NC - 1)));
 #endif
-#ifdef SSAMD_PIPE_BUILD_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     // ---- prologue: first window row staged, its e tile and its first weight chunk built (not overlapped: 1 / win of the work)
@@ -375,51 +364,18 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     if (!A.evol) build_e(i_lo, 0, nE);
     build_weights(i_lo, 0, chunk_end(0), 0);
 
-    // Thread -> (column group xg, disparity group dg), lanes along the disparity groups.  Round 3: a tile at the left
-    // image border only has candidates up to d = x (x - d >= 0, _passive.cpp:56), so its threads are dealt over the
-    // DGe <= DG disparity groups that hold any: the waves beyond XG * DGe threads skip the tap loops altogether (x tile 0
-    // of a 1080p / D 0..192 frame: 30 of 49 groups, 8 of 12 waves; the round-2 mapping kept every wave busy with dead
-    // candidates there).  The LDS layout does not depend on the mapping.  (xg, dg) are worked out ONCE and carried in one
-    // register: two integer divisions per window row were 1.3 % of the kernel's instructions.
-    const int DGe = max(1, min(g.DG, (min(min(x0 + Tx, W) - 1, x0 + Tx - 1) - dlo) / ASW_RD + 1));
-    const int nact = g.XG * DGe;
-    int pk_xd;
-    bool run;          // does this wave hold any candidate the reference evaluates?  (wave-uniform, see asw_aggregate_kernel)
-    {
-        const int tidm = threadIdx.x;
-        int xg, dg;
-#ifdef SSAMD_PIPE_PLAIN_LANES          // round-2 order (A/B builds of tools/build_variants.sh): thread = xg * DGe + dg
-        xg = tidm / DGe; dg = tidm - xg * DGe;
-#else
-        // Lane order (round 3).  The LDS serves a ds_read_b128 in groups of 16 lanes and a ds_read_b32 in groups of 32;
-        // with thread = xg * DGe + dg and DGe no multiple of 16 (49 at 1080p / D 0..192) a third of the 16-lane groups
-        // straddle two column groups, whose right-weight blocks and e dwords then collide (rocprofv3: 23 % of the LDS
-        // cycles were bank conflicts).  Here every 16-lane group holds 16 consecutive disparity groups of ONE column
-        // group (F = DGe / 16 such groups per column group, in reversed order for odd column groups: the e rows of
-        // neighbouring column groups are half the banks apart, so pairs of 16-lane groups stay on disjoint banks);
-        // the DGe % 16 left-over disparity groups of all column groups follow at the end.
-        const int F = DGe >> 4, Lo = DGe & 15, nfull = g.XG * F;
-        const int grp16 = tidm >> 4, r16 = tidm & 15;
-        if (grp16 < nfull) {
-            xg = grp16 / F;
-            int gi = grp16 - xg * F;
-            if (xg & 1) gi = F - 1 - gi;
-            dg = 16 * gi + r16;
-        } else {
-            const int q = tidm - 16 * nfull;
-            xg = Lo ? q / Lo : g.XG;                 // (q >= XG * Lo: beyond the active threads)
-            dg = 16 * F + (Lo ? q - xg * Lo : 0);
-        }
-#endif
-        pk_xd = xg | (dg << 16);
-        const bool tile_live = tidm < nact && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
-                               x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
-        run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < nact;
-    }
-
     int cb = 0;
     for (int i = i_lo; i < i_hi; ++i) {
         const unsigned char *const eT = eT0 + (i & 1) * g.e_bytes;
+        int tidm = threadIdx.x;
+        asm volatile("" : "+v"(tidm));
+        bool run;      // does this wave hold any candidate the reference evaluates?  (wave-uniform, see asw_aggregate_kernel)
+        {
+            const int xg = tidm / g.DG, dg = tidm - xg * g.DG;
+            const bool tile_live = tidm < g.XG * g.DG && x0 + RX * xg < W && dlo + ASW_RD * dg <= A.maxD &&
+                                   x0 + RX * xg + RX - 1 - (dlo + ASW_RD * dg) >= 0;
+            run = __builtin_amdgcn_ballot_w64(tile_live) != 0 && tidm < g.XG * g.DG;
+        }
         AswRow ew[RX];
 
         for (int c = 0; c < NC; ++c) {
@@ -432,9 +388,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
             if (phase == 0) build_next(i, c, cb);
 #ifndef SSAMD_ABLATE_AGG
             if (run) {
-                // e-row and weight pointers are derived per chunk from the packed thread coordinates: nothing but those,
-                // the e window and the accumulators stays live across a build
-                const int xg = pk_xd & 0xffff, dg = pk_xd >> 16;
+                // thread coordinates, e-row pointer and swizzle state are derived per chunk from an opaque thread id:
+                // nothing but the e window and the accumulators stays live across a build
+                int tida = threadIdx.x;
+                asm volatile("" : "+v"(tida));
+                const int xg = tida / g.DG, dg = tida - xg * g.DG;
                 // the next e row to load is ul0 + RX - 1 + jc (ul0 + 0 before the priming of the window row)
                 const unsigned char *erow = eT + (RX * xg + (jc == 0 ? 0 : RX - 1 + jc)) * Se + 4 * dg;
                 if (jc == 0) {
@@ -449,25 +407,23 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
                 for (int j0 = jc; j0 < jend; j0 += RX) {
 #define SSAMD_PSTEP(JJ)                                                                             \
     if (j0 + (JJ) < jend) {                                                                         \
-        const uint32_t epk = *reinterpret_cast<const uint32_t *>(erow + (STATIC ? (JJ) * SEC : 0)); \
-        if constexpr (!STATIC) erow += Se;                                                          \
+        const uint32_t epk = *reinterpret_cast<const uint32_t *>(erow);                             \
+        erow += Se;                                                                                 \
         float wl[RX], wr[NWR];                                                                      \
         {                                                                                           \
-            const float *const wl_ = wlp + (STATIC ? (JJ) * SLC : 0);                              \
-            const float *const wr_ = wrp + (STATIC ? (JJ) * SRC : 0);                              \
-            const float4 v0 = *reinterpret_cast<const float4 *>(wl_);                              \
+            const float4 v0 = *reinterpret_cast<const float4 *>(wlp);                              \
             wl[0] = v0.x; wl[1] = v0.y; wl[2] = v0.z; wl[3] = v0.w;                                 \
-            const float4 v1 = *reinterpret_cast<const float4 *>(wl_ + 4);                          \
+            const float4 v1 = *reinterpret_cast<const float4 *>(wlp + 4);                          \
             wl[4] = v1.x; wl[5] = v1.y; wl[6] = v1.z; wl[7] = v1.w;                                 \
-            const float4 r0 = *reinterpret_cast<const float4 *>(wr_);                              \
-            const float4 r1 = *reinterpret_cast<const float4 *>(wr_ + 4);                          \
-            const float4 r2 = *reinterpret_cast<const float4 *>(wr_ + 8);                          \
+            const float4 r0 = *reinterpret_cast<const float4 *>(wrp);                              \
+            const float4 r1 = *reinterpret_cast<const float4 *>(wrp + 4);                          \
+            const float4 r2 = *reinterpret_cast<const float4 *>(wrp + 8);                          \
             asm volatile("" ::"v"(r2.w));      /* unused 12th weight: keeps the read a ds_read_b128 */ \
             wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = r0.w;                                 \
             wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = r1.w;                                 \
             wr[8] = r2.x; wr[9] = r2.y; wr[10] = r2.z; wr[11] = r2.w;                               \
         }                                                                                           \
-        if constexpr (!STATIC) { wlp += g.SL; wrp += SR; }                                         \
+        wlp += g.SL; wrp += SR;                                                                     \
         /* columns 0 .. RX-2 first: the newest e row (tap row j + RX - 1) is only used by the last column and is \
            unpacked into the registers of the oldest row once column 0 is done with that one */       \
         _Pragma("unroll") for (int xi = 0; xi < RX; ++xi) {                                         \
@@ -483,7 +439,6 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
                     SSAMD_PSTEP(0) SSAMD_PSTEP(1) SSAMD_PSTEP(2) SSAMD_PSTEP(3)
                     SSAMD_PSTEP(4) SSAMD_PSTEP(5) SSAMD_PSTEP(6) SSAMD_PSTEP(7)
 #undef SSAMD_PSTEP
-                    if constexpr (STATIC) { erow += RX * SEC; wlp += RX * SLC; wrp += RX * SRC; }
                 }
             }
 #endif
@@ -495,8 +450,8 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     // ---- weighted average (_passive.cpp:88) and the two WTA reductions (as asw_aggregate_kernel)
     int tidf = threadIdx.x;
     asm volatile("" : "+v"(tidf));
-    if (tidf < nact) {
-        const int xg = pk_xd & 0xffff, dg = pk_xd >> 16;
+    if (tidf < g.XG * g.DG) {
+        const int xg = tidf / g.DG, dg = tidf - xg * g.DG;
         u64 diag[RX + ASW_RD - 1];
 #pragma unroll
         for (int k = 0; k < RX + ASW_RD - 1; ++k) diag[k] = KEY_NONE;

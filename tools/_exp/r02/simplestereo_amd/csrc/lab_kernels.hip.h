@@ -1,0 +1,98 @@
+// K0: BGR u8 -> pixel records {L,a,b,bgrx}.  Pointwise, HBM-bound (3 B in, 16 B out
+// per pixel).  Replaces ColorConversion::ImageFromBGR2Lab
+// (reference headers/colorconversion.hpp:18-86, called at _passive.cpp:337-341).
+#pragma once
+#include "common.hip.h"
+
+namespace ssamd {
+
+// sRGB byte -> linear*100 (colorconversion.hpp:19-37).  The transfer curve only
+// depends on the byte, so it is a 256-entry table filled once by the host.
+__constant__ float c_lin100[256];
+
+// CIE f(t) with the reference's precision mix: float powf above the knee, double
+// linear segment below (colorconversion.hpp:55-65).
+// powf(t, (float)(1 / 3.0)) for t in (0.008856, ~1.1] as the correctly rounded float (up to double-rounding ties) of the
+// real power: the device library's powf spends ~150 instructions per call on a general (x, y) -- 80 % of this kernel --
+// while a cube root needs a handful.  z = t^(-1/3) by division-free Newton steps from a v_log / v_exp seed, one in fp32 and
+// one in fp64 (1e-6 -> 1e-7 -> 1e-14), c = t z^2 = t^(1/3), and the exponent's distance from 1/3, dy = (float)(1/3.0) - 1/3 =
+// 9.93e-9, enters as t^dy = 1 + dy ln t (next term 1e-16).  The reference's glibc powf is within 0.82 ulp of the same real.
+#ifndef SSAMD_LAB_LIBM_POWF
+__device__ __forceinline__ float lab_pow_third(float tf)
+{
+    const double t = (double)tf;
+    const float l2 = __builtin_amdgcn_logf(tf);                          // v_log_f32: log2(t)
+    float zf = __builtin_amdgcn_exp2f(l2 * -0.33333334f);              // t^(-1/3), ~1e-6
+    zf = zf * fmaf(-tf, zf * zf * zf, 4.0f) * 0.33333334f;              // one step in fp32: ~1e-7
+    double z = (double)zf;
+    {
+        const double z3 = z * z * z;
+        z = z * fma(-t, z3, 4.0) * (1.0 / 3.0);                          // z <- z (4 - t z^3) / 3: ~1e-14
+    }
+    const double c = t * z * z;
+    const double dy = (double)(float)(1 / 3.0) - 1.0 / 3.0;
+    return (float)fma(c * dy, (double)(l2 * 0.6931471805599453f), c);
+}
+#else
+__device__ __forceinline__ float lab_pow_third(float tf) { return powf(tf, (float)(1 / 3.0)); }
+#endif
+
+__device__ __forceinline__ double lab_f(double t)
+{
+    if (t > 0.008856) return (double)lab_pow_third((float)t);
+    return (7.787 * t) + (16.0 / 116.0);
+}
+
+__device__ __forceinline__ void bgr_to_lab(uint32_t B, uint32_t G, uint32_t R, float &L, float &a, float &b)
+{
+    const float r = c_lin100[R], g = c_lin100[G], bl = c_lin100[B];
+    // observer 2 deg / D65 matrix in fp64 (colorconversion.hpp:40-42)
+    const double X = r * 0.4124 + g * 0.3576 + bl * 0.1805;
+    const double Y = r * 0.2126 + g * 0.7152 + bl * 0.0722;
+    const double Z = r * 0.0193 + g * 0.1192 + bl * 0.9505;
+    const float refX = 95.047f, refY = 100.0f, refZ = 108.883f;   // float constants, :48
+    const double fx = lab_f(X / refX), fy = lab_f(Y / refY), fz = lab_f(Z / refZ);
+    L = (float)(116 * fy - 16);
+    a = (float)(500 * (fx - fy));
+    b = (float)(200 * (fy - fz));
+}
+
+// One thread per pixel; 4 consecutive pixels share 12 contiguous bytes but a
+// 3-byte-per-lane read is still fully coalesced at the wave level (192 B/wave).
+__global__ __launch_bounds__(256) void bgr2lab_records_kernel(const uint8_t *__restrict__ bgr,
+                                                              PixRec *__restrict__ rec, long long npix)
+{
+    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    for (; p < npix; p += stride) {
+        uint32_t B, G, R;
+        if (p + 1 < npix) {                 // one unaligned 4-byte read instead of three byte reads (the 4th byte is the next pixel's)
+            const uint32_t v = *reinterpret_cast<const u32_unaligned *>(bgr + 3 * p);
+            B = v & 0xff; G = (v >> 8) & 0xff; R = (v >> 16) & 0xff;
+        } else {
+            B = bgr[3 * p]; G = bgr[3 * p + 1]; R = bgr[3 * p + 2];
+        }
+        PixRec o;
+        bgr_to_lab(B, G, R, o.L, o.a, o.b);
+        o.bgrx = B | (G << 8) | (R << 16);
+        rec[p] = o;
+    }
+}
+
+// debug/verification: plain float32 Lab image
+__global__ __launch_bounds__(256) void bgr2lab_f32_kernel(const uint8_t *__restrict__ bgr,
+                                                          float *__restrict__ lab, long long npix)
+{
+    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; p < npix; p += stride) {
+        float L, a, b;
+        bgr_to_lab(bgr[3 * p], bgr[3 * p + 1], bgr[3 * p + 2], L, a, b);
+        lab[3 * p] = L;
+        lab[3 * p + 1] = a;
+        lab[3 * p + 2] = b;
+    }
+}
+
+}  // namespace ssamd

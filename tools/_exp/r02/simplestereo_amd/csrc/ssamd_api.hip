@@ -1,0 +1,1556 @@
+// libssamd.so: host side of the C ABI declared in include/ssamd.h (gfx950 / ROCm).
+// Owns device scratch, chooses launch geometry, launches the HIP kernels.
+// There is deliberately no CPU code path for the operators in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <list>
+#include <map>
+#include <thread>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ssamd.h"
+#include "asw_kernels.hip.h"
+#include "asw_pipe_kernel.hip.h"
+#include "asw_wave_kernel.hip.h"
+#include "asw_alt_kernels.hip.h"
+#include "gsw_kernels.hip.h"
+#include "lab_kernels.hip.h"
+#include "rig_kernels.hip.h"
+
+using namespace ssamd;
+
+namespace {
+
+thread_local std::string g_err;
+// Locking: every device has its own context and its own mutex (Ctx::mu), so one process can drive several GPUs
+// concurrently through the operators (ssamd_*_multi does, one host thread per device).  g_geom_mutex guards the
+// small process-wide launch-geometry caches only and is never held across a HIP call.
+std::mutex g_geom_mutex;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? SSAMD_ENOMEM : SSAMD_EHIP, "%s failed: %s",    \
+                        #expr, hipGetErrorString(e_));                                             \
+    } while (0)
+
+// ------------------------------------------------------------------ scratch
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SSAMD_OK;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) { ptr = nullptr; return fail(SSAMD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return SSAMD_OK;
+    }
+};
+
+struct Profile {
+    bool on = false;
+    struct Pair { hipEvent_t a, b; int slot; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[SSAMD_K_COUNT] = {0};
+    long long n[SSAMD_K_COUNT] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void drain()
+    {
+        for (auto &p : pending) {
+            float t = 0.f;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+                ms[p.slot] += t;
+                n[p.slot] += 1;
+            }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+// Small parameter-keyed device tables (ASW proximity weights per (winSize, gammaP), GSW weight table per gamma):
+// a matcher that alternates between parameter sets finds its table again instead of re-uploading it behind a
+// stream synchronisation.  An entry owns its host copy, so the upload is an ordinary asynchronous copy on the
+// calling stream; later calls on other streams are ordered behind it by ScratchOrder.
+struct TableEntry {
+    int k0 = 0; double k1 = 0;
+    DevBuf dev;
+    std::vector<float> host;
+};
+struct TableCache {
+    std::list<TableEntry> entries;       // most recently used first
+    size_t max_entries;
+    explicit TableCache(size_t n) : max_entries(n) {}
+    TableEntry *find(int k0, double k1)
+    {
+        for (auto it = entries.begin(); it != entries.end(); ++it)
+            if (it->k0 == k0 && it->k1 == k1) {
+                entries.splice(entries.begin(), entries, it);
+                return &entries.front();
+            }
+        return nullptr;
+    }
+};
+
+struct Ctx {
+    std::mutex mu;                      // serialises the calls on this device
+    int dev = -1;
+    bool lut_ready = false;
+    hipStream_t stream = nullptr;       // used by the host-buffer entry points
+    DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol, altdisp;
+    TableCache proxTabs{8}, gswTabs{4};
+    std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
+    hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
+    Profile prof;
+};
+
+Ctx g_ctx[16];
+
+// The calling thread's current HIP device is restored when an entry point returns: an operator asked to run on
+// device k must not leave the caller's later allocations or launches on device k.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// hipFuncSetAttribute costs a runtime round trip: ask only when a launch needs more dynamic LDS than the kernel
+// has been granted on this device so far
+int grant_dyn_lds(Ctx &c, const void *kernel, int bytes);
+
+struct Timed {   // brackets one kernel launch with events when profiling is on
+    Ctx &c; hipStream_t s; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Timed(Ctx &c_, hipStream_t s_, int slot_) : c(c_), s(s_), slot(slot_)
+    {
+        if (c.prof.on) { a = c.prof.get(); b = c.prof.get(); (void)hipEventRecord(a, s); }
+    }
+    ~Timed()
+    {
+        if (a) { (void)hipEventRecord(b, s); c.prof.pending.push_back({a, b, slot}); }
+    }
+};
+
+// A locked device context: makes `device` (-1: the calling thread's current one) current for the duration of the
+// entry point, takes that device's mutex and restores the caller's device afterwards.
+struct CtxLock {
+    DeviceGuard guard;                   // destroyed last: restores the caller's device after the unlock
+    std::unique_lock<std::mutex> lk;
+    Ctx *c = nullptr;
+    Ctx *operator->() { return c; }
+    Ctx &operator*() { return *c; }
+};
+
+int get_ctx(int device, CtxLock &out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SSAMD_ENODEVICE, "no HIP device visible: libssamd has no CPU fallback");
+    if (device < 0) device = out.guard.saved >= 0 ? out.guard.saved : 0;
+    if (device >= n || device >= 16) return fail(SSAMD_EINVAL, "device ordinal %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    Ctx &c = g_ctx[device];
+    out.lk = std::unique_lock<std::mutex>(c.mu);
+    out.c = &c;
+    if (c.dev < 0) {
+        c.dev = device;
+        HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c.scratch_free, hipEventDisableTiming));
+    }
+    if (!c.lut_ready) {
+        // sRGB byte -> linear*100 in the reference's float arithmetic (colorconversion.hpp:19-37)
+        float lut[256];
+        for (int v = 0; v < 256; ++v) {
+            float x = v / 255.0;
+            if (x > 0.04045) x = powf((x + 0.055) / 1.055, 2.4);
+            else x /= 12.92;
+            x *= 100;
+            lut[v] = x;
+        }
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_lin100), lut, sizeof(lut)));
+        c.lut_ready = true;
+    }
+    return SSAMD_OK;
+}
+
+int grant_dyn_lds(Ctx &c, const void *kernel, int bytes)
+{
+    int &granted = c.max_dyn_lds[kernel];
+    if (bytes <= granted || bytes <= 48 * 1024) return SSAMD_OK;     // 48 KiB need no opt-in
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    granted = bytes;
+    return SSAMD_OK;
+}
+
+// The scratch buffers (pixel records, WTA keys, tables) are shared by every call on a device.  Calls are
+// serialised on the host by the device's mutex; across streams the next call's stream waits for the previous call's
+// last kernel, so callers may use any stream without synchronising between operators.
+struct ScratchOrder {
+    Ctx &c; hipStream_t s;
+    ScratchOrder(Ctx &c_, hipStream_t s_) : c(c_), s(s_) { (void)hipStreamWaitEvent(s, c.scratch_free, 0); }
+    ~ScratchOrder() { (void)hipEventRecord(c.scratch_free, s); }
+};
+
+int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
+{
+    if (H <= 0 || W <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (!(win > 0 && win % 2 == 1)) return fail(SSAMD_EINVAL, "winSize must be a positive odd number!");
+    if (minD < 0) return fail(SSAMD_EINVAL, "minDisparity must be >= 0 (negative values are undefined behaviour in the reference)");
+    if (W > 32767 || maxD > 32767) return fail(SSAMD_ELIMIT, "width / maxDisparity exceed the int16 disparity range");
+    if (row0 < 0 || rows < 0 || row0 + rows > H) return fail(SSAMD_EINVAL, "output row range [%d,%d) outside the image (height %d)", row0, row0 + rows, H);
+    if (win > 255) return fail(SSAMD_ELIMIT, "winSize %d > 255 not supported", win);
+    if (rows > 65535) return fail(SSAMD_ELIMIT, "more than 65535 output rows per call: split the image into row strips");
+    return SSAMD_OK;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------ ASW geometry
+bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int Rx, bool e2, bool odd_pitch = false,
+                  bool pipe = false)
+{
+    g.Rx = Rx;
+    g.JC = JC >= win ? win : JC;                 // tap columns staged per chunk; win = the whole row at once
+    g.pipe = 0; g.NC = 1; g.JCmax = g.JC; g.dephase = 0; g.wave_rx = 0;
+    if (pipe) {
+        // phase-shifted kernel (asw_pipe_kernel.hip.h): chunks start at multiples of JC (8 or 16), a tail shorter than
+        // the 8-column register tile is merged into the last chunk; needs >= 2 chunks, two e tiles, the 8-column tile
+        // chunk starts are multiples of JC (itself a multiple of the register tile's columns); the chunk count is
+        // win / JC rounded, the last chunk takes what is left (win 35: JC 16 -> 16, 19; JC 8 -> 8, 8, 8, 11; JC 12 -> 12, 12, 11)
+        if (Rx != 8 || JC % Rx || !e2) return false;
+        g.NC = (win + JC / 2) / JC;
+        if (g.NC < 2 || (g.NC - 1) * JC >= win) return false;
+        g.pipe = 1;
+        // waves 0-3 build before they aggregate (see the kernel): pays with three or four waves per SIMD (12-wave
+        // groups: 1080p/193 41.8 -> 41.0 ms), costs with two (640x480/65, 8 waves: 3.11 -> 3.26 ms)
+        g.dephase = getenv("SSAMD_ASW_DEPHASE") ? atoi(getenv("SSAMD_ASW_DEPHASE")) : (round_up(XG * DG, 64) / 64 >= 12 ? 1 : 0);
+        g.JCmax = std::max(JC, win - (g.NC - 1) * JC);
+    }
+    const int wrows = g.pipe ? 2 * g.JCmax : (g.JC < win ? 2 * g.JC : win);   // chunk buffers alternate
+    const int wcols = g.JC;                      // tap columns a weight-build pass covers
+
+    const int p = win / 2;
+    g.XG = XG; g.DG = DG;
+    g.Tx = Rx * XG; g.Dc = ASW_RD * DG;
+    g.threads = round_up(XG * DG, 64);
+    g.nL = g.Tx + 2 * p;
+    g.nRc = g.Tx + g.Dc - 1;
+    g.nR = g.nRc + 2 * p;
+    // parity-split rows (asw_split_pos): two halves of ceil(n/8)*4 floats; +1 block so that the halves
+    // start on different banks phases and reads one block past the end stay inside the row
+    g.hL = ((g.Tx + 7) / 8) * 4 + 4;
+    g.SL = 2 * g.hL;
+    g.hR = ((g.nRc + 4 + 7) / 8) * 4 + 4;
+    g.SR = 2 * g.hR;
+    int P = 8;                                  // dword slots per e row: closed under XOR with emask
+    while (P < DG && P < 32) P <<= 1;           //   power of two up to 32, then multiples of 32
+    if (P < DG) P = round_up(DG, 32);
+    g.Se = 4 * P;
+    g.emask = std::min(P, 32) - 1;
+    if (odd_pitch) {                            // plain rows with an odd dword pitch instead of the XOR swizzle
+        g.Se = 4 * (DG | 1);
+        g.emask = 0;
+    }
+    if (g.pipe) {
+        // plain rows, lanes along the disparity groups (asw_pipe_kernel.hip.h): a thread reads floats
+        // [8 xg, 8 xg + 8) of a wL row and [8 xg - 4 dg + Dc - 4, + 12) of a wR row (the last one is index nRc, unused)
+        g.hL = g.hR = 0;
+        g.SL = round_up(g.Tx, 4);
+        g.SR = round_up(g.nRc + 1, 4);
+        // e rows: one dword per disparity group, pitch a multiple of 16 bytes so that a tile is an aligned contiguous
+        // block of the pre-computed volume (LDS-DMA moves 16 bytes per lane)
+        g.Se = 16 * ((DG + 3) / 4);
+        g.emask = 0;
+    }
+    // weight build balance: (centres x segments) tasks over the workgroup's threads
+    {
+        const int ncen = g.Tx + g.nRc;
+        int best_cost = 1 << 30;
+        for (int ns = 1; ns <= wcols && ns <= 8; ++ns) {
+            const int len = (wcols + ns - 1) / ns, rounds = (ncen * ns + g.threads - 1) / g.threads;
+            const int cost = rounds * (round_up(len, ASW_WB) + 2);       // evaluated in batches of ASW_WB
+            if (cost < best_cost) { best_cost = cost; g.wseg = ns; g.wlen = len; }
+        }
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_wL = take((size_t)wrows * g.SL * 4);
+    g.off_wR = take((size_t)wrows * g.SR * 4);
+    g.e_bytes = (int)(((size_t)g.nL * g.Se + 15) & ~(size_t)15);
+    g.e2 = (e2 && g.JC < win && (win + g.JC - 1) / g.JC >= 2) ? 1 : 0;
+    if (g.pipe && !g.e2) return false;
+    g.off_e = take((size_t)g.e_bytes * (g.e2 ? 2 : 1));
+    g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
+    g.off_labR = take((size_t)g.nR * 16 * 2);
+    g.off_bgrL = take((size_t)g.nL * 4 * 2);
+    g.off_bgrR = take((size_t)g.nR * 4 * 2);
+    g.off_bestL = take((size_t)g.Tx * 8);
+    g.off_bestR = take((size_t)(g.nRc + 1) * 8);
+    g.off_cen = take((size_t)(g.Tx + g.nRc) * 16);
+    g.off_prox = take((size_t)win * 4 * 2);      // one window row of proximity weights, double-buffered
+    g.lds_bytes = (int)off;
+    return off <= limit;
+}
+
+// Chunked geometries first try two e tiles (no row-start barrier, asw_kernels.hip.h); when that does not fit the
+// LDS budget they fall back to one.
+bool asw_layout(AswGeom &g, int win, int XG, int DG, size_t limit, int JC = 1 << 20, int Rx = ASW_RX, bool odd_pitch = false)
+{
+    if (!getenv("SSAMD_ASW_NO_E2") && asw_layout_e(g, win, XG, DG, limit, JC, Rx, true, odd_pitch) && g.e2) return true;
+    return asw_layout_e(g, win, XG, DG, limit, JC, Rx, false, odd_pitch);
+}
+
+// Average number of LDS passes of the aggregation loop's e-row read (one dword per lane; a wave is served in two
+// halves of 32 lanes, a pass per distinct address that shares a bank) for an e layout: lanes = consecutive thread
+// ids, thread (xg, dg) reads dword dg (XOR-swizzled with row / Rx & emask) of row Rx*xg + n.
+double asw_e_read_passes(const AswGeom &g)
+{
+    const int P = g.Se / 4, T = g.XG * g.DG;
+    long long tot = 0, cnt = 0;
+    for (int n = 0; n < g.Rx; ++n)
+        for (int base = 0; base < T; base += 32) {
+            int hits[64] = {0}, worst = 0;
+            for (int l = 0; l < 32 && base + l < T; ++l) {
+                const int tid = base + l, xg = tid % g.XG, dg = tid / g.XG, ul = g.Rx * xg + n;
+                worst = std::max(worst, ++hits[(ul * P + (dg ^ ((ul / g.Rx) & g.emask))) & 63]);
+            }
+            tot += worst; ++cnt;
+        }
+    return cnt ? (double)tot / cnt : 1.0;
+}
+
+// The e-tile scheme is decided for the chosen tile only (the search prices LDS with the swizzled form): rows with an
+// odd dword pitch are smaller (DG|1 instead of a power of two / multiple of 32 dwords) and often conflict less for
+// narrow thread grids; the XOR swizzle wins for wide ones.  Take the odd pitch when it makes room for a second e
+// tile, or when it does not read slower.
+void asw_pick_e_scheme(AswGeom &g, int win)
+{
+    if (getenv("SSAMD_ASW_XOR_ONLY")) return;
+    AswGeom alt;
+    if (!asw_layout(alt, win, g.XG, g.DG, 160 * 1024, g.JC >= win ? (1 << 20) : g.JC, g.Rx, true)) return;
+    // two e tiles (one barrier less per window row: 1080p/193 45.96 -> 44.7 ms) outweigh a few bank conflicts of a
+    // one-dword read; among equals the layout with fewer passes wins
+    const bool take = alt.e2 != g.e2 ? alt.e2 > g.e2 : asw_e_read_passes(alt) <= asw_e_read_passes(g) + 1e-9;
+    if (take) {
+        alt.nchunks = g.nchunks;
+        g = alt;
+    }
+}
+
+// Phase-shifted kernel for a chosen tile (asw_pipe_kernel.hip.h): same XG x DG thread grid and register tile, tap
+// columns in chunks of 8 (or 16) with the tail merged, two e tiles.  Taken whenever it fits (8-column tile, window of
+// at least two chunks, LDS); the sums and their order are those of asw_aggregate_kernel, so maps do not change.
+// SSAMD_ASW_PIPE=0 disables it, =8 / =16 force the chunk length (experiments and tests).
+void asw_try_pipe(AswGeom &g, int win)
+{
+    int want = -1;
+    if (const char *env = getenv("SSAMD_ASW_PIPE")) want = atoi(env);
+    if (want == 0 || g.Rx != 8) return;
+    for (int JC : {16, 8}) {
+        if (want > 0 && JC != want) continue;
+        // chunks of 8 double the barriers per window row: measured to pay only with three waves per SIMD
+        // (4096x2160/257: 265 -> 245 ms, 1080p/129/win 21: 12.7 -> 11.3 ms; 8-wave tiles lose 5-15 %)
+        if (want < 0 && JC == 8 && round_up(g.XG * g.DG, 64) / 64 < 12) continue;
+        AswGeom alt;
+        if (!asw_layout_e(alt, win, g.XG, g.DG, 160 * 1024, JC, 8, true, false, true)) continue;
+        alt.nchunks = g.nchunks;
+        g = alt;
+        return;
+    }
+}
+
+// Wave-autonomous kernel for small disparity ranges (asw_wave_kernel.hip.h): geometry of one wave's strip and its
+// slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
+static constexpr int ASW_WAVE_MAX_DG = 12;
+bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
+{
+    g.RX = rx;
+    const int p = win / 2;
+    g.DG = (nD + ASW_RD - 1) / ASW_RD;
+    if (g.DG < 1 || g.DG > ASW_WAVE_MAX_DG) return false;
+    g.NXG = 64 / g.DG;
+    g.Txw = rx * g.NXG;
+    g.Dc = ASW_RD * g.DG;
+    g.lanes = g.NXG * g.DG;
+    g.nLw = g.Txw + 2 * p;
+    g.nRcw = g.Txw + g.Dc - 1;
+    g.nRw = g.nRcw + 2 * p;
+    g.SLw = round_up(g.Txw, 64);                   // weight rows padded to whole 64-lane build rounds
+    g.SRw = round_up(g.nRcw + 1, 64);
+    // bytes per e column: an odd number of dwords, so that the e dwords the lanes of a wave read in one step (column
+    // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
+    // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
+    g.Se = 4 * (g.DG | 1);
+    g.waves = getenv("SSAMD_ASW_WAVE_WG") ? std::max(1, std::min(4, atoi(getenv("SSAMD_ASW_WAVE_WG")))) : 1;
+    // order matters: the build's last trip reads up to 127 entries past the end of the centres and of each pixel
+    // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_w = take((size_t)(g.SLw + g.SRw) * 4 * 2);        // two rows: tap columns j and j + 1
+    g.off_cen = take((size_t)(g.Txw + g.nRcw) * 16);
+    g.off_pixL = take((size_t)g.nLw * 16);
+    g.off_pixR = take((size_t)g.nRw * 16);
+    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(129 + 2 * p) * 16) + (size_t)rx * g.Se);
+    // the winner arrays are only used after the last window row: they share the pixel rows' space
+    g.off_bestL = g.off_pixL;
+    g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
+    if ((size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8 > off) off = (size_t)g.off_bestR + (size_t)(g.nRcw + 1) * 8;
+    g.wave_lds = (int)((off + 15) & ~(size_t)15);
+    return (size_t)g.wave_lds * g.waves <= 160 * 1024;
+}
+
+// Which wave kernel (0: none) serves a window / disparity range.  Measured on 1080p and VGA frames, windows 11..35
+// (profiles/r02_wave_sweep.txt): the wave kernel beats the workgroup kernels up to 48 disparities; the 4-column tile
+// (more waves per SIMD, half the LDS per wave) wins up to 16 disparities, the 8-column tile above.
+// SSAMD_ASW_WAVE=0 disables it, SSAMD_ASW_WAVE_RX=8|4 forces a tile (experiments / tests); SSAMD_ASW_EVOL=0 (in-kernel e
+// tiles) also disables it, the wave kernel needs the TAD volume.
+static constexpr int ASW_WAVE_MAX_ND = 48;
+int asw_wave_pick(int win, int nD)
+{
+    if (getenv("SSAMD_ASW_WAVE") && atoi(getenv("SSAMD_ASW_WAVE")) == 0) return 0;
+    if (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0) return 0;
+    if (nD < 1 || nD > ASW_WAVE_MAX_ND || win > 63) return 0;
+    AswWaveGeom wg;
+    if (const char *env = getenv("SSAMD_ASW_WAVE_RX")) {
+        const int rx = atoi(env);
+        return (rx == 8 || rx == 4) && asw_wave_layout(wg, win, nD, rx) ? rx : 0;
+    }
+    const int first = nD <= 16 ? 4 : 8, second = 12 - first;
+    if (asw_wave_layout(wg, win, nD, first)) return first;
+    return asw_wave_layout(wg, win, nD, second) ? second : 0;
+}
+
+// Pick the workgroup tile (XG column groups x DG disparity groups, nchunks disparity chunks)
+// with an occupancy-aware cost model calibrated on MI355X (profiles/r01_*):
+//   - the kernel needs 168 VGPRs -> 3 waves per SIMD; a workgroup of w waves puts ceil(w/4)
+//     on each SIMD, so k = min(floor(3 / ceil(w/4)), floor(160 KiB / LDS)) workgroups are
+//     resident per CU.  Measured: 2 x 6-wave groups do NOT co-reside (87 ms), one 12-wave
+//     group does (55 ms) on the 1080p/193/35 workload.
+//   - per window row a thread spends M cycles aggregating and B cycles building weights / e
+//     tiles; B shrinks with the tile (fewer window centres per (x,d) pair).
+//   - padding of the disparity range, idle lanes, partial x tiles and the last partial wave of
+//     workgroups over the 256 CUs are charged as lost throughput.
+int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::vector<AswGeom> *shortlist = nullptr);
+
+// The search walks a few thousand candidate tiles (0.1-0.3 ms on the host): remember the answer per problem shape,
+// a video stream asks the same question every frame.  (Both maps are guarded by g_geom_mutex.)
+std::map<std::array<int, 4>, AswGeom> g_asw_geom_cache;
+std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached geometry was picked by measurement
+// autotuning mode: 1 always, 0 never, -1 (default) only for small problems, where the ~50 trial launches cost
+// at most about 0.2 s once and where the cost model is least reliable
+std::atomic<int> g_autotune{getenv("SSAMD_AUTOTUNE") ? (atoi(getenv("SSAMD_AUTOTUNE")) > 0 ? 1 : (atoi(getenv("SSAMD_AUTOTUNE")) < 0 ? -1 : 0)) : -1};
+constexpr double ASW_AUTOTUNE_SMALL_TAPS = 3.0e10;      // window taps per call (about 3-4 ms of kernel time)
+
+// experiment / test hooks that force a kernel form: such calls neither read nor write the geometry cache and are not autotuned
+bool asw_geometry_forced() { return getenv("SSAMD_ASW_GEOM") || getenv("SSAMD_ASW_WAVE") || getenv("SSAMD_ASW_WAVE_RX"); }
+
+int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
+{
+    if (asw_geometry_forced()) return asw_search_geometry(best, W, rows, win, nD);          // tuning hooks: never cached
+    std::lock_guard<std::mutex> glk(g_geom_mutex);
+    const std::array<int, 4> key{W, rows, win, nD};
+    auto it = g_asw_geom_cache.find(key);
+    if (it != g_asw_geom_cache.end()) { best = it->second; return SSAMD_OK; }
+    const int rc = asw_search_geometry(best, W, rows, win, nD);
+    if (rc == SSAMD_OK) {
+        if (g_asw_geom_cache.size() > 256) { g_asw_geom_cache.clear(); g_asw_geom_tuned.clear(); }
+        g_asw_geom_cache[key] = best;
+    }
+    return rc;
+}
+
+// shortlist (autotuning): the best-scoring geometry of every structurally different class of candidates
+// (register tile, tap-column chunking, disparity chunks, waves per group), best classes first
+int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::vector<AswGeom> *shortlist)
+{
+    std::map<std::array<int, 4>, std::pair<double, AswGeom>> classes;
+    // tuning hook: SSAMD_ASW_GEOM="XG,DG[,JC[,RX]]" forces the tile shape (experiments and tests only)
+    if (const char *env = getenv("SSAMD_ASW_GEOM")) {
+        int XG = 0, DG = 0, JCe = 1 << 20, Rx = ASW_RX;
+        if (sscanf(env, "%d,%d,%d,%d", &XG, &DG, &JCe, &Rx) >= 2 && XG > 0 && DG > 0 && XG * DG <= ASW_MAX_THREADS &&
+            (Rx == 8 || Rx == 4)) {
+            if (JCe <= 0 || JCe % Rx) JCe = 1 << 20;
+            if (!asw_layout(best, win, XG, DG, 160 * 1024, JCe, Rx)) return fail(SSAMD_ELIMIT, "SSAMD_ASW_GEOM does not fit LDS");
+            best.nchunks = (nD + best.Dc - 1) / best.Dc;
+            asw_pick_e_scheme(best, win);
+            asw_try_pipe(best, win);
+            return SSAMD_OK;
+        }
+    }
+    const double c_tap = 10.9, c_w = 70.0, c_e = 60.0, c_stage = 40.0;   // cycles (one SIMD lane-slot)
+    double best_score = -1.0;
+    bool found = false;
+    for (int nch = 1; nch <= nD; ++nch) {
+        const int per = (nD + nch - 1) / nch;
+        const int DG = round_up(per, ASW_RD) / ASW_RD;
+        if (DG > 128) continue;
+        if ((nD + DG * ASW_RD - 1) / (DG * ASW_RD) != nch) continue;
+        // register tile 8x4 (168 VGPRs: 3 waves per SIMD), or 4x4 (<= 128 VGPRs: 4 waves per SIMD, twice the
+        // threads per tile column) for small disparity ranges, where LDS capacity bounds the resident waves
+        // (measured, 1080p / win 35: D 0..16 16.7 -> 10.5 ms, D 0..32 14.3 -> 13.2 ms, D 0..47 17.2 -> 14.7 ms,
+        //  D 0..64 no gain)
+        for (int Rx : {8, 4}) {
+        if (Rx == 4 && nD > 56) continue;
+        const int max_wps = Rx == 8 ? 3 : 4;
+        const int xg_cap = std::min(ASW_MAX_THREADS / DG, (W + Rx - 1) / Rx);
+        const int pipe_env = getenv("SSAMD_ASW_PIPE") ? atoi(getenv("SSAMD_ASW_PIPE")) : -1;
+        for (int XG = xg_cap; XG >= 1; --XG)
+        for (int cand = 0; cand < 6; ++cand) {
+            // candidates 0-3: asw_aggregate_kernel with whole window rows or tap-column chunks of 16 / 8 / 4;
+            // candidates 4-5: the phase-shifted kernel (8-column tile) with chunks of 16 / 8
+            static const int jcs[6] = {1 << 20, 16, 8, 4, 16, 8};
+            const int JC = jcs[cand];
+            const bool piped = cand >= 4;
+            AswGeom g;
+            if (piped) {
+                if (Rx != 8 || pipe_env == 0 || (pipe_env > 0 && pipe_env != JC)) continue;
+                if (pipe_env < 0 && JC == 8 && round_up(XG * DG, 64) / 64 < 12) continue;      // see asw_try_pipe
+                if (!asw_layout_e(g, win, XG, DG, 160 * 1024, JC, 8, true, false, true)) continue;
+            } else {
+                if (JC < (1 << 20) && (JC >= win || JC % Rx)) continue;
+                if (!asw_layout(g, win, XG, DG, 160 * 1024, JC, Rx)) continue;
+            }
+            g.nchunks = nch;
+            const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
+            const int k = std::min(max_wps / per_simd, (160 * 1024) / g.lds_bytes);
+            if (k < 1) continue;
+            // per-thread aggregation cycles of one window row; the 4-column tile spends the same address and
+            // e-row work on half the taps; the phase-shifted kernel's step is 107 instead of 111 instructions
+            // with a third of the bank conflicts
+            const double M = (double)win * Rx * ASW_RD * (Rx == 8 ? (piped ? 0.93 * c_tap : c_tap) : c_tap * 1.15);
+            const int ncen = g.Tx + g.nRc;
+            const int njc = piped ? g.NC : (win + g.JC - 1) / g.JC;     // weight-build passes (= barriers) per window row
+            double B;
+            if (piped)      // no e tiles (TAD volume), one centre per thread, the build partly under other waves' taps
+                B = (double)ncen * win / g.threads * 28.0 + njc * 350.0 + c_stage;
+            else
+                B = (double)njc * ((ncen * g.wseg + g.threads - 1) / g.threads) * (round_up(g.wlen, ASW_WB) + 2) * c_w +
+                    (njc > 1 ? njc * 400.0 : 0.0) +               // extra barriers of the chunked form
+                    (double)((g.nL * (g.Dc / 4) + g.threads - 1) / g.threads) * c_e +
+                    (double)((g.nL + g.nR + g.threads - 1) / g.threads) * c_stage;
+            const double d_util = (double)nD / ((double)nch * g.Dc);
+            const int xt = (W + g.Tx - 1) / g.Tx;
+            const double x_util = (double)W / ((double)xt * g.Tx);
+            const double nwg = (double)xt * std::max(rows, 1) * nch, slots = 256.0 * k;
+            const double tail = nwg / (std::ceil(nwg / slots) * slots);
+            const double overlap = k > 1 ? 1.05 : 1.0;             // independent groups hide each other's build phase
+            // the busiest SIMD carries k*per_simd waves: a group's time scales with per_simd, and fewer
+            // resident waves hide less latency (measured: 2 waves/SIMD ~0.85x, 1 wave/SIMD ~0.6x of 3)
+            const int wps = k * per_simd;
+            const double occ = wps >= 3 ? 1.0 : (wps == 2 ? 0.85 : 0.6);
+            const double useful = (double)win * Rx * ASW_RD * c_tap;        // = M for the 8-column tile
+            const double score = (double)XG * DG / per_simd * occ * (useful / (M + B)) * d_util * x_util * tail * overlap;
+            if (score > best_score) { best_score = score; best = g; found = true; }
+            if (shortlist) {
+                auto &slot = classes[{piped ? 80 : Rx, std::min(g.JC, 64), nch, waves}];
+                if (score > slot.first) slot = {score, g};
+            }
+        }
+        }
+        if (DG <= 2) break;
+    }
+    // Measured exception to the cost model: with the 8-column tile and many disparity groups (DG >= 33, i.e. narrow
+    // x tiles under long weight rows) staging the tap columns in chunks of 16 is 1-1.5 % FASTER than whole rows --
+    // build and aggregation phases of different waves interleave (1080p/193: 46.9 -> 46.2 ms, 4K/257: 271.9 -> 269.2 ms,
+    // 1080p/129: 32.4 -> 32.0 ms) -- while for DG <= 25 it is 4-6 % slower, as the model says.
+    if (found && !best.pipe && best.Rx == 8 && best.JC >= win && best.DG >= 33 && win > 16) {
+        AswGeom g;
+        if (asw_layout(g, win, best.XG, best.DG, 160 * 1024, 16, 8)) {
+            g.nchunks = best.nchunks;
+            best = g;
+        }
+    }
+    if (found && !best.pipe) asw_pick_e_scheme(best, win);      // (the phase-shifted form competed in the search above)
+    // small disparity ranges: the wave kernel takes over (the workgroup geometry stays as its fallback)
+    const int wave_rx = found ? asw_wave_pick(win, nD) : 0;
+    if (wave_rx) best.wave_rx = wave_rx;
+    if (shortlist && found) {
+        std::vector<std::pair<double, AswGeom>> v;
+        for (auto &kv : classes) v.push_back(kv.second);
+        std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        shortlist->clear();
+        if (wave_rx) {          // the model's choice first, then the other tile of the wave kernel, then workgroup geometries
+            shortlist->push_back(best);
+            AswWaveGeom wg;
+            if (!getenv("SSAMD_ASW_WAVE_RX") && asw_wave_layout(wg, win, nD, 12 - wave_rx)) {
+                AswGeom other = best;
+                other.wave_rx = 12 - wave_rx;
+                shortlist->push_back(other);
+            }
+        }
+        // every class enters in its phase-shifted form where that exists AND in the plain form: which of the two is
+        // faster depends on the tile (waves per SIMD, centres per thread), and the trials measure it
+        // (next to the wave kernel only the three best workgroup classes: they have not won a trial for such ranges)
+        for (size_t i = 0; i < v.size() && i < (wave_rx ? 3u : 12u) && v[i].first > 0.6 * best_score; ++i) {
+            if (!v[i].second.pipe) asw_pick_e_scheme(v[i].second, win);
+            v[i].second.wave_rx = 0;
+            shortlist->push_back(v[i].second);
+        }
+    }
+    return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no ASW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
+}
+
+// Proximity weights exp(-|t|/gammaP) of the window taps (_passive.cpp:360-364), cached per (winSize, gammaP).
+int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
+{
+    if (TableEntry *e = c.proxTabs.find(win, gammaP)) { *out = (const float *)e->dev.ptr; return SSAMD_OK; }
+    if (c.proxTabs.entries.size() >= c.proxTabs.max_entries) {
+        // evicting frees device memory a launch in flight may still read: the one place that waits (rare: more
+        // than eight parameter sets alternating on one device)
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(c.proxTabs.entries.back().dev.ptr);
+        c.proxTabs.entries.pop_back();
+    }
+    c.proxTabs.entries.emplace_front();
+    TableEntry &e = c.proxTabs.entries.front();
+    e.k0 = win; e.k1 = gammaP;
+    const int p = win / 2;
+    e.host.resize((size_t)win * win);
+    for (int i = 0; i < win; ++i)
+        for (int j = 0; j < win; ++j) {
+            const double di = i - p, dj = j - p;
+            e.host[(size_t)i * win + j] = (float)std::exp(-std::sqrt(di * di + dj * dj) / gammaP);
+        }
+    int rc = e.dev.reserve(e.host.size() * 4);
+    if (rc) { c.proxTabs.entries.pop_front(); return rc; }
+    hipError_t he = hipMemcpyAsync(e.dev.ptr, e.host.data(), e.host.size() * 4, hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) {
+        (void)hipFree(e.dev.ptr);
+        c.proxTabs.entries.pop_front();
+        return fail(SSAMD_EHIP, "hipMemcpyAsync(proximity table) failed: %s", hipGetErrorString(he));
+    }
+    *out = (const float *)e.dev.ptr;
+    return SSAMD_OK;
+}
+
+int launch_lab_records(Ctx &c, const uint8_t *d_img, PixRec *rec, int W, int r0, int r1, hipStream_t s)
+{
+    const long long npix = (long long)(r1 - r0) * W;
+    if (npix <= 0) return SSAMD_OK;
+    const int blocks = (int)std::min<long long>((npix + 255) / 256, 256 * 8);
+    Timed t(c, s, SSAMD_K_LAB);
+    hipLaunchKernelGGL(bgr2lab_records_kernel, dim3(blocks), dim3(256), 0, s, d_img + (size_t)r0 * W * 3,
+                       rec + (size_t)r0 * W, npix);
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_disp, hipStream_t s,
+                    int16_t *d_raw_right = nullptr)
+{
+    if (rows <= 0) return SSAMD_OK;
+    Timed t(c, s, slot);
+    if (d_raw_right) {          // verification dump: both raw argmins instead of the left-right check and filling
+        const long long n = (long long)rows * W;
+        const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyL.ptr, d_disp, rows, W, 0);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyR.ptr, d_raw_right, rows, W, 1);
+    } else if (lrcheck) {
+        const size_t lds = (((size_t)W * 2 + 15) & ~(size_t)15) + W;      // up to 96 KiB at the 32767-column limit
+        int rc = grant_dyn_lds(c, (const void *)lr_check_fill_kernel, (int)lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lr_check_fill_kernel, dim3(rows), dim3(256), lds, s, (const u64 *)c.keyL.ptr,
+                           (const u64 *)c.keyR.ptr, d_disp, rows, W);
+    } else {
+        const long long n = (long long)rows * W;
+        const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(wta_decode_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)c.keyL.ptr, d_disp, rows, W, 0);
+    }
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
+                    int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
+                    float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr)
+{
+    int rc = check_common(H, W, win, minD, maxD, row0, rows);
+    if (rc) return rc;
+    if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
+    // alternate-rows mode: row0 is matched exactly, then every second row; the range must end with an exact row or with
+    // the image (asw_alternate_rows arranges that for strips)
+    if (alternate && d_costs) return fail(SSAMD_EINVAL, "the alternate-rows mode has no cost dump");
+    if (rows == 0) return SSAMD_OK;
+    ScratchOrder order(c, s);
+    const int p = win / 2, nD = maxD - minD + 1;
+    const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
+
+    // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
+    // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
+    AswArgs a;
+    const int grows = alternate ? (rows + 1) / 2 : rows;              // workgroup rows: every row, or the even ones
+    if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, grows, win, nD))) return rc;
+    // Autotuning (ssamd_autotune): the first call for a problem shape times the best geometry of every class of
+    // candidates on the real buffers and keeps the fastest.  Every geometry accumulates the same taps in the same
+    // order, so the result does not depend on the choice (and the trial launches are idempotent).
+    const std::array<int, 4> shape{W, grows, win, nD};
+    std::vector<AswGeom> trial;
+    const double call_taps = (double)W * grows * nD * win * win;
+    const int tune_mode = g_autotune.load();
+    const bool tune_now = tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS);
+    bool tuned_already;
+    { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_asw_geom_tuned.count(shape) != 0; }
+    if (tune_now && nD >= 1 && !asw_geometry_forced() && !tuned_already) {
+        AswGeom tmp;
+        if (asw_search_geometry(tmp, W, grows, win, nD, &trial) != SSAMD_OK || trial.size() < 2) trial.clear();
+    }
+    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent; };
+    bool need_keys = !is_direct(a.g) || alternate;  // the alternate mode merges its odd-row jobs through the left keys
+    for (const AswGeom &g : trial) need_keys = need_keys || !is_direct(g);
+    if (need_keys) {
+        if ((rc = c.keyL.reserve(nout * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+    }
+    if (consistent) {
+        if ((rc = c.keyR.reserve(nout * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+    }
+
+    if (nD >= 1) {
+        if ((rc = c.recL.reserve(npix * sizeof(PixRec)))) return rc;
+        if ((rc = c.recR.reserve(npix * sizeof(PixRec)))) return rc;
+        const float *d_prox = nullptr;
+        if ((rc = get_prox(c, win, gammaP, s, &d_prox))) return rc;
+        const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
+        if ((rc = launch_lab_records(c, dL, (PixRec *)c.recL.ptr, W, r0, r1, s))) return rc;
+        if ((rc = launch_lab_records(c, dR, (PixRec *)c.recR.ptr, W, r0, r1, s))) return rc;
+
+        a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
+        a.prox = d_prox;
+        a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+        a.costs = d_costs;
+        a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
+        a.kC = (float)(-1.4426950408889634 / gammaC);
+        a.ystep = alternate ? 2 : 1;
+        a.evol = nullptr; a.erow0 = r0; a.erows = r1 - r0; a.evolW = 0;
+        // pre-computed truncated-absolute-difference volume for the phase-shifted kernel (asw_tad_volume_kernel);
+        // SSAMD_ASW_EVOL=0 keeps the in-kernel e tiles (experiments / tests)
+        AswWaveArgs wa;
+        auto prepare_evol = [&](const AswGeom &g) -> int {
+            a.evol = nullptr;
+            int chunks = g.nchunks, Tx = g.Tx, Dc = g.Dc, Se = g.Se;
+            if (g.wave_rx) {
+                if (!asw_wave_layout(wa.g, win, nD, g.wave_rx)) return fail(SSAMD_ELIMIT, "wave kernel geometry does not fit LDS");
+                chunks = 1; Tx = wa.g.Txw; Dc = wa.g.Dc; Se = wa.g.Se;
+            } else if (!g.pipe || (getenv("SSAMD_ASW_EVOL") && atoi(getenv("SSAMD_ASW_EVOL")) == 0)) {
+                return SSAMD_OK;
+            }
+            const int xt = (W + Tx - 1) / Tx;
+            const int evolW = round_up(xt * Tx + 2 * p, 4);           // rows stay 16-byte aligned for any Se
+            const size_t bytes = (size_t)chunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)Se;
+            if (bytes > ((size_t)24 << 30)) {
+                if (g.wave_rx) return fail(SSAMD_ELIMIT, "TAD volume of %zu bytes is too large", bytes);
+                return SSAMD_OK;                                      // very large frames: build the tiles in the kernel
+            }
+            int erc = c.evol.reserve(bytes + 4096);                     // + one DMA piece of slack behind the last tile
+            if (erc) return erc;
+            a.evol = (const unsigned char *)c.evol.ptr;
+            a.evolW = evolW;
+            Timed t(c, s, SSAMD_K_LAB);
+            const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), (unsigned)chunks);
+            const size_t elds = (size_t)(2 * TADV_COLS + Dc) * 4;
+            hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), elds, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
+                               (unsigned char *)c.evol.ptr, W, p, minD, Dc, Se, r0, r1 - r0, evolW);
+            HIP_TRY(hipGetLastError());
+            return SSAMD_OK;
+        };
+        auto launch = [&](const AswGeom &g) -> int {
+            a.g = g;
+            a.keyL = is_direct(g) ? nullptr : (u64 *)c.keyL.ptr;
+            a.disp = is_direct(g) ? d_disp : nullptr;
+            if (g.wave_rx) {                  // (prepare_evol(g) filled wa.g and built the volume)
+                wa.recL = a.recL; wa.recR = a.recR; wa.prox = a.prox;
+                wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs;
+                wa.evol = a.evol; wa.erow0 = a.erow0; wa.erows = a.erows; wa.evolW = a.evolW;
+                wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
+                wa.ystep = a.ystep; wa.kC = a.kC;
+                auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
+                                       : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
+                // build rounds known at compile time (straight-line build): the common combinations
+                const int kl = (wa.g.Txw + 63) / 64, kr = (wa.g.nRcw + 63) / 64;
+                const bool unrolled = !(getenv("SSAMD_ASW_WAVE_UNROLL") && atoi(getenv("SSAMD_ASW_WAVE_UNROLL")) == 0);
+                if (unrolled && !d_costs) {
+                    const int key = wa.g.RX * 100 + kl * 10 + kr;
+                    if (key == 822) wk = asw_aggregate_wave_kernel<false, 8, 2, 2>;         // 17..28 disparities (class default)
+                    else if (key == 812) wk = asw_aggregate_wave_kernel<false, 8, 1, 2>;    // 29..48
+                    else if (key == 412) wk = asw_aggregate_wave_kernel<false, 4, 1, 2>;    // 13..20
+                    else if (key == 422) wk = asw_aggregate_wave_kernel<false, 4, 2, 2>;    // 9..12
+                    else if (key == 423) wk = asw_aggregate_wave_kernel<false, 4, 2, 3>;    // 5..8
+                }
+                const int lds = wa.g.wave_lds * wa.g.waves, xt = (W + wa.g.Txw - 1) / wa.g.Txw;
+                if (int grc = grant_dyn_lds(c, (const void *)wk, lds)) return grc;
+                hipLaunchKernelGGL(wk, dim3((xt + wa.g.waves - 1) / wa.g.waves, grows, 1), dim3(64 * wa.g.waves), lds, s, wa);
+                HIP_TRY(hipGetLastError());
+                return SSAMD_OK;
+            }
+            const dim3 grid((W + g.Tx - 1) / g.Tx, grows, g.nchunks), block(g.threads);
+            const bool chunked = g.JC < win;
+            if (g.pipe) {
+                auto pk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
+                if (int grc = grant_dyn_lds(c, (const void *)pk, g.lds_bytes)) return grc;
+                hipLaunchKernelGGL(pk, grid, block, g.lds_bytes, s, a);
+                HIP_TRY(hipGetLastError());
+                return SSAMD_OK;
+            }
+            auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
+                                : (d_costs ? asw_aggregate_kernel<true, false> : asw_aggregate_kernel<false, false>);
+            if (g.Rx == 4)
+                kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true, 4> : asw_aggregate_kernel<false, true, 4>)
+                               : (d_costs ? asw_aggregate_kernel<true, false, 4> : asw_aggregate_kernel<false, false, 4>);
+            if (int grc = grant_dyn_lds(c, (const void *)kern, g.lds_bytes)) return grc;
+            hipLaunchKernelGGL(kern, grid, block, g.lds_bytes, s, a);
+            HIP_TRY(hipGetLastError());
+            return SSAMD_OK;
+        };
+        if (!trial.empty()) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            // round-robin over the candidates, several rounds, fastest launch of each: clocks ramp up during the
+            // first launches after an idle period, so timing the candidates one after the other would favour the
+            // late ones
+            std::vector<float> cand_ms(trial.size(), 3.0e38f);
+            for (const AswGeom &g : trial) { (void)prepare_evol(g); (void)launch(g); }    // code load, clocks, scratch
+            for (int round = 0; round < 4; ++round)
+                for (size_t ci = 0; ci < trial.size(); ++ci) {
+                    float ms = 3.0e38f;
+                    if (hipEventRecord(e0, s) == hipSuccess && prepare_evol(trial[ci]) == SSAMD_OK && launch(trial[ci]) == SSAMD_OK &&
+                        hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (round > 0) cand_ms[ci] = std::min(cand_ms[ci], ms);  // round 0 is warm-up
+                }
+            AswGeom fastest = a.g;
+            float best_ms = 3.0e38f;
+            for (size_t ci = 0; ci < trial.size(); ++ci)
+                // the model's own choice (first) keeps the job unless another candidate is clearly faster
+                if (cand_ms[ci] < best_ms * (ci == 0 ? 1.0f : 0.985f)) { best_ms = cand_ms[ci]; fastest = trial[ci]; }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            {
+                std::lock_guard<std::mutex> glk(g_geom_mutex);
+                g_asw_geom_cache[shape] = fastest;
+                g_asw_geom_tuned[shape] = true;
+            }
+            a.g = fastest;
+        }
+        {
+            const AswGeom final_geom = a.g;
+            if ((rc = prepare_evol(final_geom))) return rc;
+            Timed t(c, s, SSAMD_K_ASW_AGG);
+            if ((rc = launch(final_geom))) return rc;
+        }
+    }
+    const bool direct = is_direct(a.g);
+    if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
+    if (alternate && rows > 1) {
+        // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
+        // empty disparity range the decode already wrote x everywhere and the fill reproduces it.
+        AswAltArgs f;
+        const size_t nodd = (size_t)(rows / 2) * W;
+        if ((double)nodd * ((nD + 7) / 8 + 1) >= 4.0e9)
+            return fail(SSAMD_ELIMIT, "alternate-rows mode: image x disparity range too large for the 32-bit job counter");
+        f.cap = (unsigned int)std::min<size_t>(std::max<size_t>(nodd, 1 << 16), 1u << 28);   // jobs of 8 candidates
+        if (const char *env = getenv("SSAMD_ALT_QUEUE_CAP"))        // test hook: a tiny queue forces the in-place path
+            f.cap = (unsigned int)std::max(1, atoi(env));
+        if ((rc = c.altq.reserve((size_t)f.cap * 8 + 16))) return rc;
+        f.ctr = (unsigned int *)c.altq.ptr; f.queue = (u64 *)((char *)c.altq.ptr + 16);
+        HIP_TRY(hipMemsetAsync(f.ctr, 0, 16, s));
+        f.recL = (const PixRec *)c.recL.ptr; f.recR = (const PixRec *)c.recR.ptr; f.prox = a.prox;
+        f.disp = d_disp; f.key = (u64 *)c.keyL.ptr;
+        f.H = H; f.W = W; f.win = win; f.pad = p; f.minD = minD; f.maxD = maxD; f.row0 = row0; f.rows = rows;
+        f.kC = (float)(-1.4426950408889634 / gammaC);
+        const dim3 pix_grid((W + 255) / 256, rows / 2);
+        Timed t(c, s, SSAMD_K_ASW_ALT);
+        hipLaunchKernelGGL(asw_alt_scan_kernel, pix_grid, dim3(256), 0, s, f);
+        hipLaunchKernelGGL(asw_alt_jobs_kernel, dim3(256 * 8), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(asw_alt_decode_kernel, pix_grid, dim3(256), 0, s, f);
+        HIP_TRY(hipGetLastError());
+    }
+    return SSAMD_OK;
+}
+
+
+// The alternate-rows mode on a row range of a (sub-)image.  row_parity = parity of the sub-image's row 0 in the whole
+// image: rows whose index in the whole image is even are matched exactly, the odd ones are filled from their two exact
+// neighbours -- so a range that starts or ends with an odd row also needs the exact row just outside it (the caller's
+// halo is winSize/2 + 1 rows then).  Those rows are computed into a scratch map and the requested rows copied out.
+int asw_alternate_rows(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int row_parity, int win,
+                       int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp, hipStream_t s)
+{
+    int rc = check_common(H, W, win, minD, maxD, row0, rows);
+    if (rc) return rc;
+    if (rows == 0) return SSAMD_OK;
+    const bool top_odd = ((row0 + row_parity) & 1) != 0, bottom_odd = ((row0 + rows - 1 + row_parity) & 1) != 0;
+    if (top_odd && row0 == 0)
+        return fail(SSAMD_EINVAL, "alternate rows: the first output row is an odd row of the image, the sub-image must start at least one row above it");
+    const int e0 = top_odd ? row0 - 1 : row0, e1 = bottom_odd ? std::min(H, row0 + rows + 1) : row0 + rows;
+    if (e0 == row0 && e1 == row0 + rows)
+        return asw_device_impl(c, dL, dR, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent, d_disp, nullptr, s, true);
+    ScratchOrder order(c, s);
+    if ((rc = c.altdisp.reserve((size_t)(e1 - e0) * W * 2))) return rc;
+    rc = asw_device_impl(c, dL, dR, H, W, e0, e1 - e0, win, maxD, minD, gammaC, gammaP, consistent, (int16_t *)c.altdisp.ptr, nullptr, s, true);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_disp, (const int16_t *)c.altdisp.ptr + (size_t)(row0 - e0) * W, (size_t)rows * W * 2, hipMemcpyDeviceToDevice, s));
+    return SSAMD_OK;
+}
+
+// ------------------------------------------------------------ GSW
+bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit)
+{
+    const int p = win / 2;
+    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = Ty == 2 ? 4 : 8;
+    g.Tx = GSW_RX * XG; g.Dc = g.Rd * DG;
+    g.threads = round_up(XG * DG, 64);
+    g.nL = g.Tx + 2 * p;
+    g.nT = g.nL + g.Dc - 1;
+    int P = 1;
+    while (8 * P < g.Dc) P <<= 1;
+    g.Se = 8 * P;                                  // floats per e row (slots of 8 disparities)
+    g.Ses = 3;
+    while ((1 << g.Ses) < g.Se) ++g.Ses;
+    g.emask = std::min(P, 32) - 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
+    g.off_w = take((size_t)Ty * win * g.Tx * 4);
+    const int nL4 = round_up(g.nL, 4);                 // the e tasks cover 4 columns
+    g.off_e = take((size_t)nL4 * g.Se * 4);
+    g.off_ref = take((size_t)nL4 * 16 * 2);            // pixel staging is double-buffered (prefetch of the next image row)
+    g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16 * 2);
+    g.off_best = take((size_t)Ty * g.Tx * 8);
+    g.lds_bytes = (int)off;
+    return off <= limit;
+}
+
+// Launch geometry of the GSW kernel: strip height Ty, XG x DG thread grid.  Relative cost model of one
+// strip, per thread: every image row of the strip pays the e tile once (c_e per element), every
+// (output row, window row) pair pays its weights (c_w per element) and its taps (c_tap per cell).
+int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD);
+
+int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)      // cached like asw_choose_geometry
+{
+    static std::map<std::array<int, 4>, GswGeom> cache;
+    if (getenv("SSAMD_GSW_GEOM")) return gsw_search_geometry(best, W, rows, win, nD);
+    std::lock_guard<std::mutex> glk(g_geom_mutex);
+    const std::array<int, 4> key{W, rows, win, nD};
+    auto it = cache.find(key);
+    if (it != cache.end()) { best = it->second; return SSAMD_OK; }
+    const int rc = gsw_search_geometry(best, W, rows, win, nD);
+    if (rc == SSAMD_OK) {
+        if (cache.size() > 256) cache.clear();
+        cache[key] = best;
+    }
+    return rc;
+}
+
+int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
+{
+    if (const char *env = getenv("SSAMD_GSW_GEOM")) {           // experiment hook: "XG,DG,Ty"
+        int XG = 0, DG = 0, Ty = 1;
+        if (sscanf(env, "%d,%d,%d", &XG, &DG, &Ty) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) &&
+            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024)) {
+            best.nchunks = (nD + best.Dc - 1) / best.Dc;
+            return SSAMD_OK;
+        }
+        return fail(SSAMD_EINVAL, "SSAMD_GSW_GEOM=%s is not a usable geometry", env);
+    }
+    const double c_tap = 5.3, c_w = 60.0, c_e = 70.0;
+    double best_score = -1.0;
+    bool found = false;
+    for (int Ty = 1; Ty <= 2; ++Ty) {
+        if (Ty > std::max(rows, 1)) break;
+        const int Rd = Ty == 2 ? 4 : 8;
+        for (int nch = 1; nch <= nD; ++nch) {
+            const int per = (nD + nch - 1) / nch;
+            const int DG = round_up(per, Rd) / Rd;
+            if (DG > 64) continue;
+            if ((nD + DG * Rd - 1) / (DG * Rd) != nch) continue;
+            const int xg_cap = std::min(GSW_MAX_THREADS / DG, (W + GSW_RX - 1) / GSW_RX);
+            for (int XG = xg_cap; XG >= 1; --XG) {
+                GswGeom g;
+                if (!gsw_layout(g, win, XG, DG, Ty, 160 * 1024)) continue;
+                g.nchunks = nch;
+                const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
+                const int k = std::min({4 / per_simd, (160 * 1024) / g.lds_bytes, 8});   // <= 128 VGPRs: 4 waves per SIMD
+                if (k < 1) continue;
+                const double M = (double)win * GSW_RX * Rd * c_tap;
+                const double Bw = (double)((g.Tx * win + g.threads - 1) / g.threads) * c_w;
+                const double Be = (double)((g.nL * g.Dc + g.threads - 1) / g.threads) * c_e;
+                const double strip = (double)(win + Ty - 1) * Be + (double)Ty * win * (M + Bw);
+                const double eff = (double)Ty * win * M / strip;
+                const double d_util = (double)nD / ((double)nch * g.Dc);
+                const int xt = (W + g.Tx - 1) / g.Tx, yt = (std::max(rows, 1) + Ty - 1) / Ty;
+                const double x_util = (double)W / ((double)xt * g.Tx);
+                const double y_util = (double)std::max(rows, 1) / ((double)yt * Ty);
+                const double nwg = (double)xt * yt * nch, slots = 256.0 * k;
+                const double tail = nwg / (std::ceil(nwg / slots) * slots);
+                const double score = (double)k * XG * DG * eff * d_util * x_util * y_util * tail;
+                if (score > best_score) { best_score = score; best = g; found = true; }
+            }
+            if (DG <= 1) break;
+        }
+    }
+    return found ? SSAMD_OK : fail(SSAMD_ELIMIT, "no GSW launch geometry fits LDS for winSize=%d nD=%d", win, nD);
+}
+
+// support weight as a function of the integer squared colour distance, in the reference's
+// arithmetic: fl32 distance (sqrt in double), float division by gamma, float exp (_passive.cpp:457-463, 495)
+int get_gsw_table(Ctx &c, int gamma, hipStream_t s, const float **out)
+{
+    if (TableEntry *e = c.gswTabs.find(gamma, 0.0)) { *out = (const float *)e->dev.ptr; return SSAMD_OK; }
+    if (c.gswTabs.entries.size() >= c.gswTabs.max_entries) {
+        HIP_TRY(hipDeviceSynchronize());         // see get_prox
+        (void)hipFree(c.gswTabs.entries.back().dev.ptr);
+        c.gswTabs.entries.pop_back();
+    }
+    c.gswTabs.entries.emplace_front();
+    TableEntry &e = c.gswTabs.entries.front();
+    e.k0 = gamma; e.k1 = 0.0;
+    e.host.resize(GSW_TAB_SIZE);
+    for (int v = 0; v < GSW_TAB_SIZE; ++v) {
+        const float dist = (float)(0.0f + std::sqrt((double)v));
+        e.host[v] = expf(-dist / gamma);
+    }
+    int rc = e.dev.reserve(e.host.size() * 4);
+    if (rc) { c.gswTabs.entries.pop_front(); return rc; }
+    hipError_t he = hipMemcpyAsync(e.dev.ptr, e.host.data(), e.host.size() * 4, hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) {
+        (void)hipFree(e.dev.ptr);
+        c.gswTabs.entries.pop_front();
+        return fail(SSAMD_EHIP, "hipMemcpyAsync(GSW weight table) failed: %s", hipGetErrorString(he));
+    }
+    *out = (const float *)e.dev.ptr;
+    return SSAMD_OK;
+}
+
+int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win, int maxD,
+                    int minD, int gamma, float fMax, int iterations, int16_t *d_disp, hipStream_t s)
+{
+    int rc = check_common(H, W, win, minD, maxD, row0, rows);
+    if (rc) return rc;
+    if (gamma == 0) return fail(SSAMD_EINVAL, "gamma must be non-zero");
+    if (rows == 0) return SSAMD_OK;
+    ScratchOrder order(c, s);
+    const int p = win / 2, nD = maxD - minD + 1;
+    const size_t npix = (size_t)H * W, nout = (size_t)rows * W;
+    if ((rc = c.keyL.reserve(nout * 8)) || (rc = c.keyR.reserve(nout * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+    HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+    if (nD >= 1) {
+        // packed pixels live in the (larger) ASW record buffers: 4 B/pixel
+        if ((rc = c.recL.reserve(npix * 4)) || (rc = c.recR.reserve(npix * 4))) return rc;
+        const float *d_tab = nullptr;
+        if ((rc = get_gsw_table(c, gamma, s, &d_tab))) return rc;
+        const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
+        const long long np = (long long)(r1 - r0) * W;
+        const int blocks = (int)std::min<long long>((np + 255) / 256, 256 * 8);
+        {
+            Timed t(c, s, SSAMD_K_LAB);
+            hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3,
+                               (uint32_t *)c.recL.ptr + (size_t)r0 * W, np);
+            hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dR + (size_t)r0 * W * 3,
+                               (uint32_t *)c.recR.ptr + (size_t)r0 * W, np);
+            HIP_TRY(hipGetLastError());
+        }
+        GswArgs a;
+        if ((rc = gsw_choose_geometry(a.g, W, rows, win, nD))) return rc;
+        a.tab = d_tab;
+        a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
+        a.iterations = iterations; a.fMax = fMax;
+        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + a.g.Ty - 1) / a.g.Ty, a.g.nchunks), block(a.g.threads);
+        auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
+        if ((rc = grant_dyn_lds(c, (const void *)kernel, a.g.lds_bytes))) return rc;
+        for (int pass = 0; pass < 2; ++pass) {
+            a.right = pass;
+            a.ref = (const uint32_t *)(pass ? c.recR.ptr : c.recL.ptr);
+            a.tgt = (const uint32_t *)(pass ? c.recL.ptr : c.recR.ptr);
+            a.key = (u64 *)(pass ? c.keyR.ptr : c.keyL.ptr);
+            Timed t(c, s, SSAMD_K_GSW_AGG);
+            hipLaunchKernelGGL(kernel, grid, block, a.g.lds_bytes, s, a);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return launch_finalize(c, SSAMD_K_GSW_FIN, true, rows, W, d_disp, s);   // consistency is unconditional in GSW
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+namespace {
+
+// ---- host-buffer paths: H2D copy of rows [in0, in1) of both images, kernels on output rows [o0, o1), D2H copy.
+// Used for the whole image (ssamd_asw / ssamd_gsw) and, one host thread per device, for the row strips of
+// ssamd_*_multi: output row y needs input rows y-pad .. y+pad only and the left-right check and occlusion filling
+// are row-local (_passive.cpp:38-40, 60-62, 251-285), so a strip that carries its halo reproduces the rows of the
+// whole-image result bit for bit.
+struct HostJob {
+    const uint8_t *img1, *img2;
+    int H, W, win, maxD, minD;
+    int o0, o1;                    // output rows of the full image
+    int16_t *disparity;            // full-image output [H][W]
+    // ASW
+    double gammaC, gammaP; int consistent; float *costs; bool alternate;
+    int16_t *raw_right;            // verification dump (ssamd_asw_argmins): raw right-referenced matches, full image
+    // GSW
+    int gamma; float fMax; int iterations;
+};
+
+int asw_host_rows(const HostJob &j, int device)
+{
+    CtxLock c;
+    int rc = get_ctx(device, c);
+    if (rc) return rc;
+    if ((rc = check_common(j.H, j.W, j.win, j.minD, j.maxD, j.o0, j.o1 - j.o0))) return rc;
+    const int p = j.win / 2 + (j.alternate ? 1 : 0);        // alternate rows: + the exact row beyond an odd first / last row
+    const int in0 = std::max(0, j.o0 - p), in1 = std::min(j.H, j.o1 + p), rows = j.o1 - j.o0;
+    const size_t nb = (size_t)(in1 - in0) * j.W * 3, nout = (size_t)rows * j.W;
+    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
+    const size_t ncost = j.costs ? nout * (size_t)std::max(1, j.maxD - j.minD + 1) : 0;
+    if (j.costs && (rc = c->costs.reserve(ncost * 4))) return rc;
+    if (j.raw_right && (rc = c->lab.reserve(nout * 2))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, j.img1 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, j.img2 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    if (j.costs) HIP_TRY(hipMemsetAsync(c->costs.ptr, 0xFF, ncost * 4, s));      // 0xFFFFFFFF = NaN
+    if (j.alternate)
+        rc = asw_alternate_rows(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows, in0 & 1,
+                                j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr, s);
+    else
+        rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
+                             j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr,
+                             j.costs ? (float *)c->costs.ptr : nullptr, s, false,
+                             j.raw_right ? (int16_t *)c->lab.ptr : nullptr);
+    if (rc) return rc;
+    if (j.raw_right)
+        HIP_TRY(hipMemcpyAsync(j.raw_right + (size_t)j.o0 * j.W, c->lab.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    if (j.disparity)
+        HIP_TRY(hipMemcpyAsync(j.disparity + (size_t)j.o0 * j.W, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    if (j.costs) HIP_TRY(hipMemcpyAsync(j.costs, c->costs.ptr, ncost * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int gsw_host_rows(const HostJob &j, int device)
+{
+    CtxLock c;
+    int rc = get_ctx(device, c);
+    if (rc) return rc;
+    if ((rc = check_common(j.H, j.W, j.win, j.minD, j.maxD, j.o0, j.o1 - j.o0))) return rc;
+    const int p = j.win / 2, in0 = std::max(0, j.o0 - p), in1 = std::min(j.H, j.o1 + p), rows = j.o1 - j.o0;
+    const size_t nb = (size_t)(in1 - in0) * j.W * 3, nout = (size_t)rows * j.W;
+    if ((rc = c->imgL.reserve(nb)) || (rc = c->imgR.reserve(nb)) || (rc = c->disp.reserve(nout * 2))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, j.img1 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, j.img2 + (size_t)in0 * j.W * 3, nb, hipMemcpyHostToDevice, s));
+    rc = gsw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
+                         j.win, j.maxD, j.minD, j.gamma, j.fMax, j.iterations, (int16_t *)c->disp.ptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(j.disparity + (size_t)j.o0 * j.W, c->disp.ptr, nout * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+// Contiguous row strips whose heights differ by at most one row (empty when there are more devices than rows) --
+// the same cut as simplestereo_amd/strips.py::strip_bounds.  One host thread per strip: each takes its own device's lock, so the
+// copies and kernels of all devices overlap.  The first failing strip's code and message are returned.
+int run_strips(const HostJob &job, const int *devices, int n_devices, int (*fn)(const HostJob &, int))
+{
+    if (!devices || n_devices < 1) return fail(SSAMD_EINVAL, "devices must name at least one GPU");
+    if (n_devices > 16) return fail(SSAMD_EINVAL, "at most 16 devices");
+    for (int a = 0; a < n_devices; ++a) {
+        if (devices[a] < 0) return fail(SSAMD_EINVAL, "devices[%d] = %d: explicit non-negative ordinals only", a, devices[a]);
+        // test hook SSAMD_MULTI_ALLOW_REPEAT: a 1-GPU box exercises the strip cut with one device listed several
+        // times (the strips then simply queue on that device's mutex)
+        for (int b = 0; b < a && !getenv("SSAMD_MULTI_ALLOW_REPEAT"); ++b)
+            if (devices[a] == devices[b]) return fail(SSAMD_EINVAL, "device %d listed twice", devices[a]);
+    }
+    int rc = check_common(job.H, job.W, job.win, job.minD, job.maxD, 0, job.H);
+    if (rc) return rc;
+    const int base = job.H / n_devices, extra = job.H % n_devices;
+    std::vector<int> codes(n_devices, SSAMD_OK);
+    std::vector<std::string> msgs(n_devices);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_devices; ++k) {
+        HostJob j = job;
+        j.o0 = k * base + std::min(k, extra);
+        j.o1 = j.o0 + base + (k < extra ? 1 : 0);
+        if (j.o1 <= j.o0) continue;                      // more devices than rows: nothing for this one
+        const int dev = devices[k];
+        th.emplace_back([j, dev, k, fn, &codes, &msgs]() {
+            codes[k] = fn(j, dev);
+            if (codes[k]) msgs[k] = g_err;               // thread-local message of the worker
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_devices; ++k)
+        if (codes[k]) return fail(codes[k], "strip %d on device %d: %s", k, devices[k], msgs[k].c_str());
+    return SSAMD_OK;
+}
+
+HostJob asw_job(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, double gammaC,
+                double gammaP, int consistent, int16_t *disparity, float *costs, bool alternate)
+{
+    HostJob j{};
+    j.img1 = img1; j.img2 = img2; j.H = H; j.W = W; j.win = win; j.maxD = maxD; j.minD = minD; j.o0 = 0; j.o1 = H;
+    j.disparity = disparity; j.gammaC = gammaC; j.gammaP = gammaP; j.consistent = consistent; j.costs = costs;
+    j.alternate = alternate;
+    return j;
+}
+
+HostJob gsw_job(const uint8_t *img1, const uint8_t *img2, int H, int W, int win, int maxD, int minD, int gamma, float fMax,
+                int iterations, int16_t *disparity)
+{
+    HostJob j{};
+    j.img1 = img1; j.img2 = img2; j.H = H; j.W = W; j.win = win; j.maxD = maxD; j.minD = minD; j.o0 = 0; j.o1 = H;
+    j.disparity = disparity; j.gamma = gamma; j.fMax = fMax; j.iterations = iterations;
+    return j;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssamd_abi_version(void) { return SSAMD_ABI_VERSION; }
+const char *ssamd_last_error(void) { return g_err.c_str(); }
+
+int ssamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ssamd_kernel_name(int slot)
+{
+    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_kernel + asw_tad_volume_kernel", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
+                                               "asw finalize (wta_decode / lr_check_fill)",
+                                               "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
+                                               "asw_alt_fill_kernel"};
+    return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
+}
+
+int ssamd_autotune(int on)
+{
+    return g_autotune.exchange(on > 0 ? 1 : (on < 0 ? -1 : 0));
+}
+
+int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
+{
+    if (!out) return fail(SSAMD_EINVAL, "out is NULL");
+    int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
+    if (rc) return rc;
+    const int nD = maxDisparity - minDisparity + 1;
+    if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
+    AswGeom g;
+    if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
+    out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
+    out[5] = (width + g.Tx - 1) / g.Tx; out[6] = rows; out[7] = g.nchunks;
+    AswWaveGeom wg;
+    if (g.wave_rx && asw_wave_layout(wg, winSize, nD, g.wave_rx)) {      // a "tile" = the four strips of a workgroup's waves
+        out[0] = wg.Txw * wg.waves; out[1] = wg.Dc; out[2] = 1; out[3] = 64 * wg.waves; out[4] = wg.wave_lds * wg.waves;
+        out[5] = (width + out[0] - 1) / out[0]; out[7] = 1;
+    }
+    return SSAMD_OK;
+}
+
+int ssamd_asw_kernel_form(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
+{
+    if (!out) return fail(SSAMD_EINVAL, "out is NULL");
+    int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
+    if (rc) return rc;
+    const int nD = maxDisparity - minDisparity + 1;
+    if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
+    AswGeom g;
+    if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
+    out[0] = g.pipe; out[1] = g.Rx; out[2] = g.JC >= winSize ? 0 : g.JC; out[3] = g.pipe ? g.dephase : 0;
+    out[4] = g.wave_rx;
+    if (g.wave_rx) { out[0] = 0; out[1] = g.wave_rx; out[2] = 0; out[3] = 0; }
+    return SSAMD_OK;
+}
+
+int ssamd_gsw_geometry(int width, int rows, int winSize, int maxDisparity, int minDisparity, int *out)
+{
+    if (!out) return fail(SSAMD_EINVAL, "out is NULL");
+    int rc = check_common(1 << 14, width, winSize, minDisparity, maxDisparity, 0, 0);
+    if (rc) return rc;
+    const int nD = maxDisparity - minDisparity + 1;
+    if (nD < 1) return fail(SSAMD_EINVAL, "empty disparity range");
+    GswGeom g;
+    if ((rc = gsw_choose_geometry(g, width, rows, winSize, nD))) return rc;
+    out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
+    out[5] = (width + g.Tx - 1) / g.Tx; out[6] = (rows + g.Ty - 1) / g.Ty; out[7] = g.nchunks; out[8] = g.Ty;
+    return SSAMD_OK;
+}
+
+int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
+                     int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
+                           gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream);
+}
+
+int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+              int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                                 disparity, nullptr, false), device);
+}
+
+int ssamd_asw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                    const int *devices, int n_devices)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return run_strips(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                              disparity, nullptr, false), devices, n_devices, asw_host_rows);
+}
+
+int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                        int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                                 disparity, nullptr, true), device);
+}
+
+int ssamd_asw_alternate_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int winSize,
+                               int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
+                               int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    return asw_device_impl(*c, d_img1, d_img2, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC,
+                           gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream, true);
+}
+
+int ssamd_asw_alternate_rows_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                                    int row_parity, int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP,
+                                    int consistent, int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (row_parity != 0 && row_parity != 1) return fail(SSAMD_EINVAL, "row_parity must be 0 or 1");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    return asw_alternate_rows(*c, d_img1, d_img2, height, width, out_row0, out_rows, row_parity, winSize, maxDisparity, minDisparity,
+                              gammaC, gammaP, consistent, d_disparity, (hipStream_t)stream);
+}
+
+int ssamd_asw_alternate_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                              int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                              const int *devices, int n_devices)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return run_strips(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                              disparity, nullptr, true), devices, n_devices, asw_host_rows);
+}
+
+int ssamd_asw_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, double gammaC, double gammaP, float *costs, int device)
+{
+    if (!img1 || !img2 || !costs) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (maxDisparity < minDisparity) return fail(SSAMD_EINVAL, "empty disparity range");
+    return asw_host_rows(asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 0, nullptr,
+                                 costs, false), device);
+}
+
+int ssamd_asw_argmins(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                      int minDisparity, double gammaC, double gammaP, int16_t *left_disparity, int16_t *right_match,
+                      int device)
+{
+    if (!img1 || !img2 || !left_disparity || !right_match) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (maxDisparity < minDisparity) return fail(SSAMD_EINVAL, "empty disparity range");
+    HostJob j = asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, 1, left_disparity,
+                        nullptr, false);
+    j.raw_right = right_match;
+    return asw_host_rows(j, device);
+}
+
+int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device)
+{
+    if (!img || !lab || height <= 0 || width <= 0) return fail(SSAMD_EINVAL, "bad argument");
+    CtxLock c;
+    int rc = get_ctx(device, c);
+    if (rc) return rc;
+    const size_t npix = (size_t)height * width;
+    if ((rc = c->imgL.reserve(npix * 3)) || (rc = c->lab.reserve(npix * 12))) return rc;
+    hipStream_t s = c->stream;
+    ScratchOrder order(*c, s);
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img, npix * 3, hipMemcpyHostToDevice, s));
+    const int blocks = (int)std::min<size_t>((npix + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(bgr2lab_f32_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t *)c->imgL.ptr,
+                       (float *)c->lab.ptr, (long long)npix);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lab, c->lab.ptr, npix * 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                     int winSize, int maxDisparity, int minDisparity, int gamma, float fMax, int iterations, int bins,
+                     int16_t *d_disparity, void *stream)
+{
+    (void)bins;                       // never read by the reference either (_passive.cpp:410)
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    return gsw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
+                           gamma, fMax, iterations, d_disparity, (hipStream_t)stream);
+}
+
+int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+              int minDisparity, int gamma, float fMax, int iterations, int bins, int16_t *disparity, int device)
+{
+    (void)bins;
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return gsw_host_rows(gsw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gamma, fMax, iterations,
+                                 disparity), device);
+}
+
+int ssamd_gsw_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, int gamma, float fMax, int iterations, int bins, int16_t *disparity,
+                    const int *devices, int n_devices)
+{
+    (void)bins;
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    return run_strips(gsw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gamma, fMax, iterations,
+                              disparity), devices, n_devices, gsw_host_rows);
+}
+
+int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
+                           int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream)
+{
+    if (!d_src || !d_mapx || !d_mapy || !d_dst) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (interpolation != 0 && interpolation != 1) return fail(SSAMD_EINVAL, "only INTER_NEAREST (0) and INTER_LINEAR (1) are supported");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long long npix = (long long)dst_h * dst_w;
+    // (a thread owns four output pixels; the map and output pointers are 16- / 4-byte aligned: device allocations)
+    if (((uintptr_t)d_mapx | (uintptr_t)d_mapy) & 15 || ((uintptr_t)d_dst & 3)) return fail(SSAMD_EINVAL, "maps must be 16-byte and the output 4-byte aligned");
+    const int blocks = (int)std::min<long long>((npix / 4 + 255) / 256 + 1, 256 * 16);
+    Timed t(*c, s, SSAMD_K_REMAP);
+    hipLaunchKernelGGL(remap_bgr_kernel, dim3(blocks), dim3(256), 0, s, d_src, src_h, src_w, d_mapx, d_mapy, d_dst, npix,
+                       interpolation == 0 ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const double *Q, float *d_points, void *stream)
+{
+    if (!d_disparity || !Q || !d_points) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (h <= 0 || w <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Mat4 q;
+    for (int k = 0; k < 16; ++k) q.m[k] = Q[k];
+    if (h > 65535) return fail(SSAMD_ELIMIT, "more than 65535 rows");
+    if ((w & 3) == 0 && (((uintptr_t)d_disparity & 7) || ((uintptr_t)d_points & 15)))
+        return fail(SSAMD_EINVAL, "disparity / point buffers must be 8- / 16-byte aligned");
+    const int per_row = (w & 3) == 0 ? w / 4 : w;                 // threads a row needs
+    Timed t(*c, s, SSAMD_K_REPROJECT);
+    hipLaunchKernelGGL(reproject_kernel, dim3((per_row + 255) / 256, h), dim3(256), 0, s, d_disparity, d_points, h, w, q);
+    HIP_TRY(hipGetLastError());
+    return SSAMD_OK;
+}
+
+int ssamd_debug_gsw_sqrt(int n, float *out)
+{
+    if (!out || n <= 0 || n > GSW_TAB_SIZE) return fail(SSAMD_EINVAL, "bad argument");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    if ((rc = c->lab.reserve((size_t)n * 4))) return rc;
+    hipStream_t s = c->stream;
+    ScratchOrder order(*c, s);
+    hipLaunchKernelGGL(gsw_sqrt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (float *)c->lab.ptr, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->lab.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
+int ssamd_profile_enable(int on)
+{
+    for (auto &c : g_ctx) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.prof.on = on != 0;
+    }
+    return SSAMD_OK;
+}
+
+int ssamd_profile_reset(void)
+{
+    DeviceGuard guard;
+    for (auto &c : g_ctx) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.dev < 0) continue;
+        (void)hipSetDevice(c.dev);
+        c.prof.drain();
+        std::fill(c.prof.ms, c.prof.ms + SSAMD_K_COUNT, 0.0);
+        std::fill(c.prof.n, c.prof.n + SSAMD_K_COUNT, 0LL);
+    }
+    return SSAMD_OK;
+}
+
+int ssamd_profile_read(double *ms, long long *launches)
+{
+    DeviceGuard guard;
+    for (int k = 0; k < SSAMD_K_COUNT; ++k) { if (ms) ms[k] = 0; if (launches) launches[k] = 0; }
+    for (auto &c : g_ctx) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.dev < 0) continue;
+        (void)hipSetDevice(c.dev);
+        c.prof.drain();
+        for (int k = 0; k < SSAMD_K_COUNT; ++k) { if (ms) ms[k] += c.prof.ms[k]; if (launches) launches[k] += c.prof.n[k]; }
+    }
+    return SSAMD_OK;
+}
+
+}  // extern "C"

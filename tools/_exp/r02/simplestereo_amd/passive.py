@@ -1,0 +1,353 @@
+"""
+passive
+=======
+Passive stereo matchers with the API of ``simplestereo.passive`` (reference
+``simplestereo/passive.py``), executed by hand-written HIP kernels on an AMD
+MI355X through the C ABI of ``libssamd.so`` (``include/ssamd.h``).
+
+    import simplestereo_amd as ss
+    disparity = ss.passive.StereoASW(winSize=35, maxDisparity=64).compute(imgL, imgR)
+
+Same class names, keyword names, defaults, public attributes, return type
+(a fresh ``numpy.int16 [H, W]`` array) and exceptions as the reference:
+
+=====================================  ===========================================
+condition                              exception (reference ``_passive.cpp`` line)
+=====================================  ===========================================
+img not an ndarray / int arg a float   ``ValueError("Invalid input format!")`` (304, 712)
+image dtype is not uint8               ``TypeError("Wrong type input!")`` (312, 720)
+not [H,W,3] or shapes differ           ``ValueError("Wrong image dimensions!")`` (319, 727)
+winSize even or <= 0                   ``ValueError("winSize must be a positive odd number!")`` (323, 731)
+=====================================  ===========================================
+
+Documented deviations that turn undefined behaviour of the reference into
+defined behaviour: ``img2``'s dtype is checked too (the reference tests ``img1``
+twice, ``_passive.cpp:309``), non-contiguous inputs are made contiguous (the
+reference reads them as if contiguous), negative ``minDisparity`` is rejected
+(out-of-bounds reads in the reference).
+
+Extensions (not in the reference): ``compute`` also accepts two CUDA/HIP
+``torch.uint8`` tensors ``[H,W,3]`` already resident in HBM and then returns a
+``torch.int16`` tensor on the same device without any host round trip; and both
+classes take one extra trailing keyword, ``device`` (default ``None`` = the
+process's current HIP device), the GPU index that host-array calls run on.
+``compute`` of both classes also takes an optional keyword ``devices=[i, j, ...]`` (host arrays only): the frame
+is cut into one row strip per listed GPU, each strip is matched on its own device concurrently and the map is
+reassembled on the host -- bit-identical to the one-GPU result, because rows are independent jobs in the
+reference as well (``_passive.cpp:372-374``).
+``StereoASW`` also takes ``alternate`` (default ``False``): the faster
+"every other pixel" variant that the reference's docstring sketches as a todo
+(reference ``passive.py:43-46``) and never implemented.
+"""
+import ctypes
+import operator
+
+import numpy as np
+
+from . import _native
+
+__all__ = ["StereoASW", "StereoGSW", "set_autotune"]
+
+_INT_MIN, _INT_MAX = -2 ** 31, 2 ** 31 - 1
+
+
+def _c_int(v):
+    """PyArg_ParseTuple 'i': anything with __index__ that fits a C int; floats are refused.
+    Every parse failure surfaces as ValueError("Invalid input format!") (_passive.cpp:304)."""
+    try:
+        i = operator.index(v)
+    except TypeError:
+        raise ValueError("Invalid input format!") from None
+    if not _INT_MIN <= i <= _INT_MAX:
+        raise ValueError("Invalid input format!")
+    return i
+
+
+def _c_double(v):
+    """PyArg_ParseTuple 'd' / 'f': anything float() accepts."""
+    try:
+        return float(v)
+    except (TypeError, ValueError):
+        raise ValueError("Invalid input format!") from None
+
+
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+def _check_pair(img1, img2):
+    """The checks of _passive.cpp:301-321 in the reference's order; returns contiguous arrays."""
+    if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
+        raise ValueError("Invalid input format!")                       # "O!" with PyArray_Type
+    if img1.dtype != np.uint8 or img2.dtype != np.uint8:
+        raise TypeError("Wrong type input!")
+    if (img1.ndim != 3 or img2.ndim != 3 or img1.shape[2] != 3 or img2.shape[2] != 3
+            or img1.shape[0] != img2.shape[0] or img1.shape[1] != img2.shape[1]):
+        raise ValueError("Wrong image dimensions!")
+    return np.ascontiguousarray(img1), np.ascontiguousarray(img2)
+
+
+def _check_pair_tensors(t1, t2):
+    import torch
+    if t1.dtype != torch.uint8 or t2.dtype != torch.uint8:
+        raise TypeError("Wrong type input!")
+    if (t1.dim() != 3 or t2.dim() != 3 or t1.shape[2] != 3 or t2.shape[2] != 3
+            or t1.shape[0] != t2.shape[0] or t1.shape[1] != t2.shape[1] or t1.device != t2.device):
+        raise ValueError("Wrong image dimensions!")
+    return t1.contiguous(), t2.contiguous()
+
+
+def _device_index(device):
+    """None -> -1 (current device of the calling thread); otherwise a non-negative GPU index."""
+    if device is None:
+        return -1
+    i = _c_int(device)
+    if i < 0:
+        raise ValueError("device must be None or a non-negative GPU index")
+    return i
+
+
+def _device_list(devices):
+    """devices=[...] of compute(): distinct non-negative GPU indices as a C int array"""
+    try:
+        idx = [_c_int(d) for d in devices]
+    except TypeError:
+        raise ValueError("devices must be a sequence of GPU indices") from None
+    if not idx or any(i < 0 for i in idx):
+        raise ValueError("devices must be a non-empty sequence of distinct non-negative GPU indices")
+    return (ctypes.c_int * len(idx))(*idx), len(idx)
+
+
+def set_autotune(on=True):
+    """Extension: launch-geometry autotuning of ``StereoASW``.  ``True``: the first ``compute`` call of every
+    problem shape times its candidate geometries on the GPU (up to ~50 extra kernel launches, once) instead of
+    trusting the cost model; ``False``: never; ``None``: the default -- only for small calls (at most 3e10 window
+    taps, i.e. a few milliseconds of kernel time), where that costs at most ~0.2 s once.  Maps are unaffected:
+    every geometry accumulates the same taps in the same order.  Returns the previous mode (True / False / None).
+    The environment variable ``SSAMD_AUTOTUNE=1 / 0 / -1`` sets the initial mode."""
+    before = _native.lib().ssamd_autotune(-1 if on is None else (1 if on else 0))
+    return None if before < 0 else bool(before)
+
+
+def _raise_native(e):
+    if e.code == -1:
+        raise ValueError(e.message) from None
+    raise e
+
+
+class StereoASW():
+    """
+    Adaptive Support-Weight stereo matching (K. Yoon, I. Kweon, 2006) -- drop-in for
+    ``simplestereo.passive.StereoASW`` (reference ``passive.py:16-92``).
+
+    Parameters (same names, order and defaults as the reference constructor)
+    ----------
+    winSize : int
+        Edge length of the square support window in pixels; odd and positive (default 35).
+    maxDisparity : int
+        Largest disparity that is tried, inclusive (default 16).
+    minDisparity : int
+        Smallest disparity that is tried, inclusive (default 0; negative values are refused).
+    gammaC : float
+        Scale of the colour term exp(-dLab / gammaC) of the support weights (default 5).
+    gammaP : float
+        Scale of the spatial term exp(-dist / gammaP) of the support weights (default 17.5).
+    device : int or None
+        Extension: GPU index for host-array calls (default None: the current HIP device).
+    alternate : bool
+        Extension, the todo of the reference's docstring (``passive.py:43-46``): match every other image
+        row exactly and let each pixel of the rows in between search only the disparities between the
+        results above and below it (copied when they agree).  About twice as fast; not the reference's
+        output (about 2-3 % of the pixels differ on Tsukuba, bad-1.0 against the ground truth does not
+        get worse).  With ``consistent`` the exact rows go through the left-right check and the occlusion
+        filling first.  Whole images only (default False).
+    consistent : bool
+        Also match with the right image as reference, invalidate left pixels whose match does
+        not agree, and fill each invalid run with the smaller of its two valid neighbours
+        (default False).  On the GPU this costs one extra reduction, not a second aggregation,
+        because the aggregated cost is symmetric in the (left pixel, right pixel) pair.
+    """
+
+    def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
+                 device=None, alternate=False):
+        if not (winSize > 0 and winSize % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        self.device = device
+        self.alternate = alternate
+        self.winSize = winSize
+        self.maxDisparity = maxDisparity
+        self.minDisparity = minDisparity
+        self.gammaC = gammaC
+        self.gammaP = gammaP
+        self.consistent = consistent
+
+    def _params(self):
+        win, maxd, mind = _c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity)
+        gc, gp = _c_double(self.gammaC), _c_double(self.gammaP)
+        return win, maxd, mind, gc, gp, 1 if self.consistent else 0
+
+    def _alternate(self, cons):
+        return bool(getattr(self, "alternate", False))
+
+    def compute(self, img1, img2, devices=None):
+        """
+        Disparity map of a rectified BGR pair.
+
+        img1, img2: left and right image, ``numpy.uint8`` arrays ``[H, W, 3]`` in OpenCV channel
+        order (or two device tensors, see the module docstring).  Returns a new ``numpy.int16``
+        array ``[H, W]`` of left-referenced disparities.  ``devices`` (extension, host arrays only):
+        list of GPU indices that share the frame as row strips.
+        """
+        if _is_device_tensor(img1) and _is_device_tensor(img2):
+            if devices is not None:
+                raise ValueError("devices=[...] applies to host arrays; device tensors are matched where they live")
+            return self._compute_device(img1, img2)
+        lib = _native.lib()
+        if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
+            raise ValueError("Invalid input format!")
+        win, maxd, mind, gc, gp, cons = self._params()
+        dev = _device_index(getattr(self, "device", None))
+        a, b = _check_pair(img1, img2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = a.shape[:2]
+        out = np.empty((H, W), np.int16)
+        try:
+            if devices is not None:
+                arr, n = _device_list(devices)
+                multi = lib.ssamd_asw_alternate_multi if self._alternate(cons) else lib.ssamd_asw_multi
+                _native.check(multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons, out.ctypes.data, arr, n))
+                return out
+            if self._alternate(cons):
+                _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
+                                                      out.ctypes.data, dev))
+                return out
+            _native.check(lib.ssamd_asw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
+                                        out.ctypes.data, dev))
+        except _native.NativeError as e:
+            _raise_native(e)
+        return out
+
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None, row_parity=0):
+        """Operands already in HBM (torch tensors): returns a torch.int16 tensor on the device.
+        Rows [out_row0, out_row0+out_rows) of the given (sub-)image are matched.  ``row_parity`` (alternate=True only):
+        parity of the sub-image's first row in the whole image, whose even rows are the exactly matched ones; such a
+        sub-image carries ``winSize // 2 + 1`` halo rows."""
+        import torch
+        lib = _native.lib()
+        win, maxd, mind, gc, gp, cons = self._params()
+        a, b = _check_pair_tensors(t1, t2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = int(a.shape[0]), int(a.shape[1])
+        rows = H - out_row0 if out_rows is None else int(out_rows)
+        alt = self._alternate(cons)
+        out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            try:
+                if alt:
+                    _native.check(lib.ssamd_asw_alternate_rows_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows,
+                                                                      int(row_parity) & 1, win, maxd, mind, gc, gp, cons,
+                                                                      out.data_ptr(), ctypes.c_void_p(stream)))
+                    return out
+                _native.check(lib.ssamd_asw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
+                                                   maxd, mind, gc, gp, cons, out.data_ptr(),
+                                                   ctypes.c_void_p(stream)))
+            except _native.NativeError as e:
+                _raise_native(e)
+        return out
+
+
+class StereoGSW():
+    """
+    Geodesic Support-Weight matching as implemented by the reference
+    (``simplestereo.passive.StereoGSW``, reference ``passive.py:99-158``): left- and
+    right-referenced winner-take-all on geodesically weighted, truncated colour
+    distances, left-right check and occlusion filling (always on).
+
+    Parameters (same names, order and defaults as the reference constructor)
+    ----------
+    winSize : int
+        Edge length of the square support window; odd and positive (default 11).
+    maxDisparity, minDisparity : int
+        Inclusive disparity search range (defaults 16 and 0).
+    gamma : int
+        Scale of exp(-geodesic distance / gamma); must be an ``int`` because the reference parses
+        it with the "i" format (default 10).
+    fMax : int or float
+        Cap of the per-pixel colour distance (default 120).
+    iterations : int
+        Relaxation sweeps of the reference's distance transform; any value >= 1 gives the same
+        weights, 0 keeps only the window centre (default 3).
+    bins : int
+        Accepted for signature compatibility; the reference never reads it (default 20).
+    device : int or None
+        Extension: GPU index for host-array calls (default None: the current HIP device).
+    """
+
+    def __init__(self, winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20,
+                 device=None):
+        if not (winSize > 0 and winSize % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        self.device = device
+        self.winSize = winSize
+        self.gamma = gamma
+        self.maxDisparity = maxDisparity
+        self.minDisparity = minDisparity
+        self.fMax = fMax
+        self.iterations = iterations
+        self.bins = bins
+
+    def _params(self):
+        return (_c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity), _c_int(self.gamma),
+                _c_double(self.fMax), _c_int(self.iterations), _c_int(self.bins))
+
+    def compute(self, img1, img2, devices=None):
+        """Disparity map of a rectified 3-channel pair (uint8 [H,W,3]); returns int16 [H,W].
+        ``devices`` (extension, host arrays only): list of GPU indices that share the frame as row strips."""
+        if _is_device_tensor(img1) and _is_device_tensor(img2):
+            if devices is not None:
+                raise ValueError("devices=[...] applies to host arrays; device tensors are matched where they live")
+            return self._compute_device(img1, img2)
+        lib = _native.lib()
+        if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
+            raise ValueError("Invalid input format!")
+        win, maxd, mind, gamma, fmax, it, bins = self._params()
+        dev = _device_index(getattr(self, "device", None))
+        a, b = _check_pair(img1, img2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = a.shape[:2]
+        out = np.empty((H, W), np.int16)
+        try:
+            if devices is not None:
+                arr, n = _device_list(devices)
+                _native.check(lib.ssamd_gsw_multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gamma, fmax, it,
+                                                  bins, out.ctypes.data, arr, n))
+                return out
+            _native.check(lib.ssamd_gsw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gamma, fmax, it, bins,
+                                        out.ctypes.data, dev))
+        except _native.NativeError as e:
+            _raise_native(e)
+        return out
+
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None):
+        import torch
+        lib = _native.lib()
+        win, maxd, mind, gamma, fmax, it, bins = self._params()
+        a, b = _check_pair_tensors(t1, t2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        H, W = int(a.shape[0]), int(a.shape[1])
+        rows = H - out_row0 if out_rows is None else int(out_rows)
+        out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            try:
+                _native.check(lib.ssamd_gsw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
+                                                   maxd, mind, gamma, fmax, it, bins, out.data_ptr(),
+                                                   ctypes.c_void_p(stream)))
+            except _native.NativeError as e:
+                _raise_native(e)
+        return out

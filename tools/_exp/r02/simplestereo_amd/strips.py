@@ -1,0 +1,241 @@
+"""Row-strip partitioning of one stereo pair across the GPUs of a node.
+
+Output row y of ASW/GSW depends only on input rows y-pad .. y+pad of both images
+(pad = winSize // 2; reference ``_passive.cpp:38-40, 60-62``) and the left-right
+check / occlusion fill only touches row y (``:251-285``); the reference already
+treats rows as independent jobs (``:372-374``).  So the image is cut into
+contiguous strips of rows, one per rank (one process per GPU); each rank needs
+``pad`` extra *input* rows above and below its strip -- the halo -- which it
+receives from the ranks owning them, point-to-point over RCCL/xGMI
+(``torch.distributed`` backend ``nccl``; ``gloo`` on CPU for the tests).  No
+intermediate data is exchanged: a strip that carries its full halo reproduces
+the whole-image rows bit-exactly, because the kernels treat the sub-image border
+as the image border only where it *is* the image border.
+
+    own   = rows [r0, r1) of the image         (resident on this rank)
+    sub   = rows [h0, h1) = own + halos         (after exchange_halos)
+    out   = matcher rows [r0-h0, r1-h0) of sub  (strip of the disparity map)
+
+The halo exchange is one batched group of isend/irecv (ncclGroupStart/End under
+the hood), at most a few messages of pad*W*3 bytes per neighbour and image; the
+strips of the result are collected with one all_gather on equal-padded strips.
+"""
+import numpy as np
+
+__all__ = ["strip_bounds", "halo_bounds", "transfer_plan", "exchange_halos", "gather_strips", "match_strip", "matcher_pad",
+           "StripContext"]
+
+
+def strip_bounds(height, world_size, rank):
+    """Rows [r0, r1) owned by `rank`: contiguous, sizes differ by at most one row."""
+    base, extra = divmod(int(height), int(world_size))
+    r0 = rank * base + min(rank, extra)
+    r1 = r0 + base + (1 if rank < extra else 0)
+    return r0, r1
+
+
+def halo_bounds(height, r0, r1, pad):
+    """Input rows [h0, h1) needed to compute output rows [r0, r1)."""
+    if r1 <= r0:
+        return r0, r0
+    return max(0, r0 - pad), min(int(height), r1 + pad)
+
+
+def transfer_plan(height, world_size, pad):
+    """All point-to-point messages of one halo exchange.
+
+    Returns a list of ``(src_rank, dst_rank, row_begin, row_end)``: global rows
+    [row_begin,row_end) owned by src that dst needs as halo.  Deterministic and
+    identical on every rank, so sends and receives pair up without negotiation.
+    Handles strips thinner than the halo (rows then come from several ranks).
+    """
+    own = [strip_bounds(height, world_size, r) for r in range(world_size)]
+    plan = []
+    for dst in range(world_size):
+        r0, r1 = own[dst]
+        h0, h1 = halo_bounds(height, r0, r1, pad)
+        for src in range(world_size):
+            if src == dst:
+                continue
+            s0, s1 = own[src]
+            for lo, hi in ((max(h0, s0), min(r0, s1)), (max(r1, s0), min(h1, s1))):
+                if hi > lo:
+                    plan.append((src, dst, lo, hi))
+    return plan
+
+
+def exchange_halos(own_left, own_right, height, pad, rank, world_size, group=None):
+    """Assemble this rank's sub-image (strip + halo rows) of both images.
+
+    own_left / own_right: torch uint8 tensors [r1-r0, W, 3] holding the rows this
+    rank owns (CUDA tensors with the nccl backend, CPU tensors with gloo).
+    Returns ``(sub_left, sub_right, out_row0, out_rows)``.
+    """
+    import torch
+    import torch.distributed as dist
+    r0, r1 = strip_bounds(height, world_size, rank)
+    h0, h1 = halo_bounds(height, r0, r1, pad)
+    W = own_left.shape[1]
+    assert own_left.shape[0] == r1 - r0 and own_right.shape == own_left.shape
+    subs = []
+    for own in (own_left, own_right):
+        sub = torch.empty((h1 - h0, W, 3), dtype=own.dtype, device=own.device)
+        sub[r0 - h0:r1 - h0] = own
+        subs.append(sub)
+    if world_size > 1:
+        ops, keep = [], []
+        for src, dst, lo, hi in transfer_plan(height, world_size, pad):
+            for own, sub in zip((own_left, own_right), subs):
+                if src == rank:
+                    buf = own[lo - r0:hi - r0].contiguous()
+                    keep.append(buf)
+                    ops.append(dist.P2POp(dist.isend, buf, dst, group=group))
+                elif dst == rank:
+                    ops.append(dist.P2POp(dist.irecv, sub[lo - h0:hi - h0], src, group=group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+    return subs[0], subs[1], r0 - h0, r1 - r0
+
+
+def gather_strips(strip_disparity, height, rank, world_size, group=None):
+    """All-gather the per-rank disparity strips into the full [height, W] map (on every rank)."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1 and not dist.is_initialized():
+        return strip_disparity
+    W = strip_disparity.shape[1]
+    rows_max = -(-int(height) // world_size)
+    padded = torch.zeros((rows_max, W), dtype=strip_disparity.dtype, device=strip_disparity.device)
+    padded[:strip_disparity.shape[0]] = strip_disparity
+    # int16 is not a NCCL/RCCL (nor gloo) collective dtype: move the strips as raw bytes
+    wire = padded.view(torch.uint8)
+    parts = [torch.empty_like(wire) for _ in range(world_size)]
+    dist.all_gather(parts, wire, group=group)
+    out = torch.empty((int(height), W), dtype=strip_disparity.dtype, device=strip_disparity.device)
+    for r in range(world_size):
+        r0, r1 = strip_bounds(height, world_size, r)
+        out[r0:r1] = parts[r].view(strip_disparity.dtype)[:r1 - r0]
+    return out
+
+
+def matcher_pad(matcher):
+    """Halo rows a strip of this matcher needs: winSize // 2, and one more for ``StereoASW(alternate=True)``, whose
+    odd rows take their candidates from the exactly matched rows above and below."""
+    return int(matcher.winSize) // 2 + (1 if getattr(matcher, "alternate", False) else 0)
+
+
+def match_strip(matcher, own_left, own_right, height, rank, world_size, group=None, gather=True):
+    """One distributed `compute`: halo exchange -> kernels on the strip -> (optional) gather.
+
+    matcher: a ``StereoASW`` / ``StereoGSW`` instance; the tensors must be device
+    tensors (the kernels run on the tensors' GPU on the current stream).
+    """
+    pad = matcher_pad(matcher)
+    subL, subR, out_row0, out_rows = exchange_halos(own_left, own_right, height, pad, rank, world_size, group)
+    r0, _ = strip_bounds(height, world_size, rank)
+    strip = _match_rows(matcher, subL, subR, out_row0, out_rows, (r0 - out_row0) & 1)
+    return gather_strips(strip, height, rank, world_size, group) if gather else strip
+
+
+def _match_rows(matcher, subL, subR, out_row0, out_rows, row_parity=0):
+    """The kernels on one strip.  A rank whose strip is EMPTY (more ranks than image rows) has nothing to match --
+    the operators refuse a 0-row image -- but must still take part in the collectives that follow, so it returns an
+    empty int16 strip instead of raising while its peers wait in the all_gather."""
+    import torch
+    if out_rows <= 0:
+        return torch.empty((0, int(subL.shape[1])), dtype=torch.int16, device=subL.device)
+    if getattr(matcher, "alternate", False):          # row_parity: parity of the sub-image's first row in the whole image
+        return matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows, row_parity=row_parity)
+    return matcher._compute_device(subL, subR, out_row0=out_row0, out_rows=out_rows)
+
+
+class StripContext:
+    """Reusable state of one rank for repeated frames of the same geometry: the transfer plan,
+    the sub-image buffers (strip + halos) and the gather buffers are built once, so that a step is
+    two device copies, one batched isend/irecv group, the kernels and one all_gather_into_tensor.
+
+        ctx = StripContext(matcher, height, width, rank, world_size, device)
+        full = ctx.step(own_left, own_right)        # full [height, width] int16 map on every rank
+
+    With the nccl (RCCL) backend all messages move device to device.  With gloo and a GPU `device`
+    (functional tests of the multi-process flow on a box without RCCL peers) the messages are staged
+    through host buffers; the kernels still run on `device`.
+    """
+
+    def __init__(self, matcher, height, width, rank, world_size, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.matcher, self.H, self.W = matcher, int(height), int(width)
+        self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.device = torch.device(device)
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.flat_gather = backend == "nccl"                  # gloo has no all_gather_into_tensor
+        self.staged = backend == "gloo" and self.device.type != "cpu"
+        cdev = torch.device("cpu") if self.staged else self.device          # where messages live
+        self.pad = matcher_pad(matcher)
+        self.r0, self.r1 = strip_bounds(self.H, self.world, self.rank)
+        self.h0, self.h1 = halo_bounds(self.H, self.r0, self.r1, self.pad)
+        self.subL = torch.zeros((self.h1 - self.h0, self.W, 3), dtype=torch.uint8, device=self.device)
+        self.subR = torch.zeros_like(self.subL)
+        mine = [t for t in transfer_plan(self.H, self.world, self.pad) if self.rank in (t[0], t[1])]
+        self.sends = [(dst, lo - self.r0, hi - self.r0) for src, dst, lo, hi in mine if src == self.rank]
+        self.recvs = [(src, lo - self.h0, hi - self.h0) for src, dst, lo, hi in mine if dst == self.rank]
+
+        def pair(n):
+            return (torch.empty((n, self.W, 3), dtype=torch.uint8, device=cdev),
+                    torch.empty((n, self.W, 3), dtype=torch.uint8, device=cdev))
+        self.send_bufs = [pair(hi - lo) for _, lo, hi in self.sends]
+        self.recv_bufs = [pair(hi - lo) for _, lo, hi in self.recvs] if self.staged else None
+        self.rows_max = -(-self.H // self.world)
+        self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=cdev)
+        self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=cdev)
+        self.full = torch.empty((self.H, self.W), dtype=torch.int16, device=self.device)
+
+    def step(self, own_left, own_right, gather=True):
+        import torch
+        import torch.distributed as dist
+        o0, o1 = self.r0 - self.h0, self.r1 - self.h0
+        self.subL[o0:o1].copy_(own_left)
+        self.subR[o0:o1].copy_(own_right)
+        if self.world > 1 and (self.sends or self.recvs):
+            ops = []
+            for (dst, lo, hi), (bl, br) in zip(self.sends, self.send_bufs):
+                bl.copy_(own_left[lo:hi])
+                br.copy_(own_right[lo:hi])
+                ops.append(dist.P2POp(dist.isend, bl, dst, group=self.group))
+                ops.append(dist.P2POp(dist.isend, br, dst, group=self.group))
+            for k, (src, lo, hi) in enumerate(self.recvs):
+                tl, tr = self.recv_bufs[k] if self.staged else (self.subL[lo:hi], self.subR[lo:hi])
+                ops.append(dist.P2POp(dist.irecv, tl, src, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, tr, src, group=self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if self.staged:
+                for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
+                    self.subL[lo:hi].copy_(tl)
+                    self.subR[lo:hi].copy_(tr)
+        strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0, self.h0 & 1)
+        if not gather:
+            return strip
+        if self.world == 1 and not dist.is_initialized():
+            return strip
+        self.padded[:strip.shape[0]].copy_(strip)
+        # int16 is not an RCCL collective dtype: gather the strips as bytes
+        if self.flat_gather:
+            dist.all_gather_into_tensor(self.gathered.view(torch.uint8), self.padded.view(torch.uint8), group=self.group)
+        else:
+            parts = list(self.gathered.view(torch.uint8).unbind(0))
+            dist.all_gather(parts, self.padded.view(torch.uint8), group=self.group)
+        if self.H == self.rows_max * self.world and not self.staged:
+            return self.gathered.view(self.H, self.W)
+        for r in range(self.world):
+            a, b = strip_bounds(self.H, self.world, r)
+            self.full[a:b].copy_(self.gathered[r, :b - a])
+        return self.full
+
+
+def split_rows(image, world_size):
+    """Host-side helper: the list of row strips of a numpy image (views)."""
+    H = image.shape[0]
+    return [np.ascontiguousarray(image[slice(*strip_bounds(H, world_size, r))]) for r in range(world_size)]
