@@ -436,6 +436,8 @@ def main():
     ap.add_argument("--with-alternate", action="store_true",
                     help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-array (PCIe-inclusive) timings")
+    ap.add_argument("--no-bad1", action="store_true",
+                    help="skip the accuracy figure on the reference strips (profiling runs: keeps the kernel statistics to the timed launches)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU + gloo self-test of the rank launcher and the strip plumbing with a probe matcher (no GPU, "
                          "not a measurement): tests/test_bench_launcher_cpu.py")
@@ -624,7 +626,7 @@ def main():
                 line["pointwise_kernels"] = bench_pointwise.measure()
             except Exception as e:      # noqa: BLE001
                 line["pointwise_kernels"] = {"error": repr(e)[:200]}
-        if world == 1 and not use_dist:
+        if world == 1 and not use_dist and not args.no_bad1:
             try:
                 line["bad1_vs_cpu_ref"] = bad1_on_reference_strips(dev)
             except Exception as e:      # noqa: BLE001

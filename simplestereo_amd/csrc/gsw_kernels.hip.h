@@ -243,40 +243,38 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
         if (r == r_lo)
 #endif
         {
-            // tasks = (output row t of the strip, tap column j) pairs of one reference column: npair = TYS * win of them,
-            // dealt to the qw threads that share a column two at a time (their table gathers are in flight together).
-            // (Round 3: the rows are part of the deal -- with narrow tiles and tall strips a thread per (column, tap
-            // column) left a third of the threads idle and half of the gathers unused.)
+            // a thread keeps one reference column c and walks (output row of the strip, tap column) with its centre pixel
+            // fetched once per row.  (A flat deal of (row, tap column) pairs over the threads -- for tall strips of
+            // narrow tiles, where a thread per tap column leaves threads idle -- was built and measured in round 3:
+            // +2 % on two-row strips from its per-task index arithmetic; dropped together with tall strips as the default.)
             const int lanesX = min(Tx, nthr), qw = nthr / lanesX;
             const int c0 = tid % lanesX, jq = tid / lanesX;
-            const int npair = TYS * win;
             if (jq < qw) {
                 for (int c = c0; c < Tx; c += lanesX) {
                     const int x = x0 + c;
-                    for (int pb = jq; pb < npair; pb += 2 * qw) {
-                        float w[2];
-                        int dst[2];
+                    for (int t = 0; t < TYS; ++t) {          // the weights of every output row of the strip
+                        if (!(t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win)) continue;
+                        const int y = y0 + t, i = r - y + p;
+                        float *const wT = wS + t * win * Tx + c;
+                        bool reached = A.iterations > 0 && x < W;
+                        if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
+                        const GswPix cpx = gsw_pix(cenS[t * Tx + c], 1.f, 0.f);
+                        // two tap columns per batch, branch-free: their table gathers are in flight together
+                        for (int jb = jq; jb < win; jb += 2 * qw) {
+                            float w[2];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int pj = min(pb + u * qw, npair - 1);
-                            int t = 0;
-                            for (int k = 1; k < TYS; ++k) t += pj >= k * win ? 1 : 0;
-                            const int j = pj - t * win;
-                            const int y = y0 + t, i = r - y + p;
-                            const bool row_used = t < ny && (unsigned)i < (unsigned)win && pb + u * qw < npair;
-                            bool reached = A.iterations > 0 && x < W;
-                            if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
-                            const GswPix cpx = gsw_pix(cenS[t * Tx + c], 1.f, 0.f);
-                            const GswPix px = refS[c + j];          // .inside: tap column x - pad + j is in the image
-                            const bool centre = i == p && j == p;
-                            const bool gather = row_used && reached && !centre && px.inside != 0.f;
-                            const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
-                            w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
-                            dst[u] = row_used ? (t * win + j) * Tx + c : -1;
+                            for (int u = 0; u < 2; ++u) {
+                                const int j = min(jb + u * qw, win - 1);
+                                const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
+                                const bool centre = i == p && j == p;
+                                const bool gather = reached && !centre && px.inside != 0.f;
+                                const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
+                                w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
+                            }
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                if (jb + u * qw < win) wT[(jb + u * qw) * Tx] = w[u];
                         }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            if (dst[u] >= 0) wS[dst[u]] = w[u];
                     }
                 }
             }

@@ -36,6 +36,9 @@ print(json.dumps(res))
 
 
 def main():
+    others = [a for a in sys.argv[1:] if not a.isdigit()]
+    if len(others) > 1:
+        return main_many(others, int(sys.argv[-1]) if sys.argv[-1].isdigit() else 2)
     other = os.path.abspath(sys.argv[1])
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     acc = {}
@@ -51,6 +54,22 @@ def main():
         o = min(x["wall_ms"] for x in v.get("other", [{"wall_ms": float("nan")}])); t = min(x["wall_ms"] for x in v.get("this", [{"wall_ms": float("nan")}]))
         same = len({x["checksum"] for lab in v.values() for x in lab}) == 1
         print("%-10s %12.3f %12.3f   %+.1f %%  %s" % (k, o, t, 100 * (t / o - 1), "same map checksum" if same else "CHECKSUMS DIFFER"))
+
+
+def main_many(trees, rounds):
+    """several trees (label=path ...) + the working tree, alternating"""
+    specs = [(t.split("=", 1)[0], os.path.abspath(t.split("=", 1)[1])) for t in trees] + [("this", ROOT)]
+    acc = {}
+    for r in range(rounds):
+        for label, tree in specs:
+            p = subprocess.run([sys.executable, "-c", WORKER, tree, ROOT], capture_output=True, text=True)
+            if p.returncode:
+                print(label, "FAILED", p.stderr[-800:]); continue
+            for k, v in json.loads(p.stdout.strip().splitlines()[-1]).items():
+                acc.setdefault(k, {}).setdefault(label, []).append(v["wall_ms"])
+    print("%-10s" % "workload" + "".join("%12s" % l for l, _ in specs) + "   (wall ms per call, best of %d rounds)" % rounds)
+    for k, v in acc.items():
+        print("%-10s" % k + "".join("%12.3f" % min(v.get(l, [float("nan")])) for l, _ in specs))
 
 
 if __name__ == "__main__":

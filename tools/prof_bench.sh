@@ -4,7 +4,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profbench_$tag; mkdir -p $O
-CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-others $@"
+CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-others --no-e2e --no-bad1 $@"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
