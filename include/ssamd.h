@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSAMD_ABI_VERSION 2      /* 2: ssamd_set_option, ssamd_asw_gsw_host staging (round 3); the multi-device and verification entry points of round 2 */
+#define SSAMD_ABI_VERSION 2      /* 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
 
 #define SSAMD_OK 0
 #define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
