@@ -25,7 +25,7 @@ def _one_json_line(stdout):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])
 def test_bench_launches_its_own_ranks(n):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
                         "--selftest-launcher"], capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
