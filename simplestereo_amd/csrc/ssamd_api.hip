@@ -62,6 +62,7 @@ struct Tuning {
     int wave_unroll = 1;              // 0: counted build loop
     int wave_merge = 1;               // 0: left and right centres of a strip in separate build rounds (round-2 form)
     int asw_static = 1;               // 0: the phase-shifted kernel always reads its strides from the geometry (round-2 form)
+    int evol_max_mb = 0;              // 0 unset; else a cap of the TAD volume in MiB (tests of the paths taken when memory is short)
     bool no_e2 = false, xor_only = false, multi_allow_repeat = false;
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
@@ -83,6 +84,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_WAVE_UNROLL") t.wave_unroll = num(1);
     else if (name == "SSAMD_ASW_WAVE_MERGE") t.wave_merge = num(1);
     else if (name == "SSAMD_ASW_STATIC") t.asw_static = num(1);
+    else if (name == "SSAMD_ASW_EVOL_MAX_MB") t.evol_max_mb = v ? std::max(0, atoi(v)) : 0;
     else if (name == "SSAMD_ASW_NO_E2") t.no_e2 = v != nullptr;
     else if (name == "SSAMD_ASW_XOR_ONLY") t.xor_only = v != nullptr;
     else if (name == "SSAMD_MULTI_ALLOW_REPEAT") t.multi_allow_repeat = v != nullptr;
@@ -94,7 +96,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
-                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
+                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
                                     "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE"};
 
 Tuning tuning_from_env()
@@ -595,7 +597,7 @@ bool asw_geometry_forced()
 {
     const Tuning &t = tune();
     return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
-           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1;
+           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0;
 }
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
@@ -836,6 +838,25 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         AswGeom tmp;
         if (asw_search_geometry(tmp, W, grows, win, nD, &trial) != SSAMD_OK || trial.size() < 2) trial.clear();
     }
+    // The TAD volume is scratch of THIS library next to the caller's own allocations (torch's caching allocator on the
+    // same GPU): never more than 24 GiB and never more than half of what is free right now (plus what the buffer already
+    // holds).  The phase-shifted kernel builds its e tiles itself when there is no volume; the wave kernel cannot, so
+    // a range it would serve falls back to the workgroup geometry stored next to it.
+    size_t evol_limit = (size_t)24 << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) evol_limit = std::min(evol_limit, c.evol.cap + free_b / 2);
+        if (tune().evol_max_mb) evol_limit = std::min(evol_limit, (size_t)tune().evol_max_mb << 20);
+    }
+    auto wave_volume_fits = [&](const AswGeom &g) {
+        AswWaveGeom wg;
+        if (!g.wave_rx || !asw_wave_layout(wg, win, nD, g.wave_rx)) return !g.wave_rx;
+        const int xt = (W + wg.Txw - 1) / wg.Txw, erows = std::min(H, row0 + rows + win / 2) - std::max(0, row0 - win / 2);
+        return (size_t)erows * (size_t)round_up(xt * wg.Txw + 2 * (win / 2), 4) * (size_t)wg.Se + 4096 <= evol_limit;
+    };
+    if (nD >= 1 && !wave_volume_fits(a.g)) a.g.wave_rx = 0;
+    trial.erase(std::remove_if(trial.begin(), trial.end(), [&](const AswGeom &g) { return !wave_volume_fits(g); }), trial.end());
+    if (trial.size() < 2) trial.clear();
     auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent; };
     bool need_keys = !is_direct(a.g) || alternate;  // the alternate mode merges its odd-row jobs through the left keys
     for (const AswGeom &g : trial) need_keys = need_keys || !is_direct(g);
@@ -886,13 +907,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             const int xt = (W + Tx - 1) / Tx;
             const int evolW = round_up(xt * Tx + 2 * p, 4);           // rows stay 16-byte aligned for any Se
             const size_t bytes = (size_t)chunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)Se;
-            // The volume is scratch of THIS library next to the caller's own allocations (torch's caching allocator on
-            // the same GPU): never more than 24 GiB, never more than half of what is free right now (plus what the
-            // buffer already holds), and a buffer four times larger than a later call needs is given back.
-            size_t free_b = 0, total_b = 0;
-            size_t limit = (size_t)24 << 30;
-            if (bytes + 4096 > c.evol.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                limit = std::min(limit, c.evol.cap + free_b / 2);
+            // (evol_limit: see above; a buffer four times larger than a later call needs is given back)
+            const size_t limit = evol_limit;
             if (c.evol.cap > ((size_t)256 << 20) && (bytes + 4096) * 4 < c.evol.cap) {
                 (void)hipStreamSynchronize(s);                        // (earlier launches of this call may still read it)
                 c.evol.release();

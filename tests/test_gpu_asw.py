@@ -379,3 +379,20 @@ def test_autotune_changes_the_geometry_never_the_map(ss, golden_inputs):
     for g1, f in zip(got_first, forced):
         assert np.array_equal(g1, f)
     assert all(w.shape == (96, 128) for w in want)
+
+
+@pytest.mark.parametrize("shape,win,maxd,consistent", [((48, 200), 35, 60, False), ((40, 300), 21, 16, True), ((30, 2000), 35, 192, False)])
+def test_asw_without_room_for_the_tad_volume(shape, win, maxd, consistent, ss):
+    """when the device has no room for the pre-computed TAD volume (here: the cap forced down to 1 MiB) the phase-shifted
+    kernel builds its e tiles itself and a small range falls back from the wave kernel to the workgroup kernels: same maps"""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    H, W = shape
+    L, R, _ = make_pair(H, W, maxd, 9)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, consistent=consistent)
+    want = m.compute(tL, tR)
+    with _native.options(SSAMD_ASW_EVOL_MAX_MB="1"):
+        got = m.compute(tL, tR)
+    assert torch.equal(got, want)
+    assert torch.equal(m.compute(tL, tR), want)
