@@ -20,7 +20,7 @@ rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
 lib = _native.lib()
 t_end = time.time() + budget
 n = skipped = 0
-HOOKS = ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL")
+HOOKS = ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL", "SSAMD_ASW_WAVE_MERGE")
 while time.time() < t_end:
     H, W = int(rng.integers(1, 140)), int(rng.integers(1, 700))
     if rng.random() < 0.1:
@@ -52,6 +52,7 @@ while time.time() < t_end:
         wg_, unroll_ = str(rng.integers(1, 5)), str(rng.integers(0, 2))
         _native.set_option("SSAMD_ASW_WAVE_WG", wg_)
         _native.set_option("SSAMD_ASW_WAVE_UNROLL", unroll_)
+        _native.set_option("SSAMD_ASW_WAVE_MERGE", None if rng.random() < 0.7 else "0")      # round 3: merged build rounds (default) / separate
         if _native.asw_kernel_form(W, H, win, maxd, mind)["wave_kernel"] != int(rx):
             skipped += 1
             continue
