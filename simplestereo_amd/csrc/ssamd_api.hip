@@ -472,7 +472,7 @@ void asw_try_pipe(AswGeom &g, int win)
 
 // Wave-autonomous kernel for small disparity ranges (asw_wave_kernel.hip.h): geometry of one wave's strip and its
 // slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
-static constexpr int ASW_WAVE_MAX_DG = 12;
+static constexpr int ASW_WAVE_MAX_DG = 16;
 // One candidate strip: nxg column groups, left / right centres in separate build rounds or merged into one list.
 bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool merged)
 {
@@ -552,9 +552,13 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
 // Which wave kernel (0: none) serves a window / disparity range.  Measured on 1080p and VGA frames, windows 11..35
 // (profiles/r02_wave_sweep.txt): the wave kernel beats the workgroup kernels up to 48 disparities; the 4-column tile
 // (more waves per SIMD, half the LDS per wave) wins up to 16 disparities, the 8-column tile above.
+// Round 3: with the merged build rounds (two rounds for the 32 + 83..95 centres of a four-column-group strip) the wave
+// kernel also wins for 49..64 disparities -- 14.0-14.1 ms against 15.9-16.6 ms at 1080p / win 35, 2.64 vs 3.09 ms at VGA
+// (profiles/r03_wave_range_49_64_ab.txt); from 65 disparities (three column groups per wave) the phase-shifted kernel is ahead
+// again (17.2 vs 18.7 ms at D 0..64), so the limit is 16 disparity groups.
 // SSAMD_ASW_WAVE=0 disables it, SSAMD_ASW_WAVE_RX=8|4 forces a tile (experiments / tests); SSAMD_ASW_EVOL=0 (in-kernel e
 // tiles) also disables it, the wave kernel needs the TAD volume.
-static constexpr int ASW_WAVE_MAX_ND = 48;
+static constexpr int ASW_WAVE_MAX_ND = 64;
 int asw_wave_pick(int win, int nD)
 {
     if (tune().asw_wave == 0 || tune().asw_evol == 0) return 0;

@@ -204,7 +204,7 @@ def test_asw_phase_shifted_kernel_equals_the_plain_one(geom, win, ss, golden_inp
             _native.set_option(k, None)
 
 
-@pytest.mark.parametrize("shape,win,maxd", [((48, 200), 35, 60), ((36, 1000), 27, 150), ((30, 2000), 35, 192)])
+@pytest.mark.parametrize("shape,win,maxd", [((48, 200), 35, 70), ((36, 1000), 27, 150), ((30, 2000), 35, 192)])
 def test_asw_tad_volume_equals_the_in_kernel_e_tiles(shape, win, maxd, ss):
     """the phase-shifted kernel fed by LDS-DMA from the pre-computed TAD volume (asw_tad_volume_kernel: 16-byte stores,
     rows of whole 16-byte blocks) computes the map of the same kernel building its e tiles itself (SSAMD_ASW_EVOL=0)"""
@@ -226,7 +226,8 @@ def test_asw_tad_volume_equals_the_in_kernel_e_tiles(shape, win, maxd, ss):
 
 @pytest.mark.parametrize("win,maxd,mind,consistent", [(35, 16, 0, False), (35, 16, 0, True), (21, 7, 0, True), (9, 3, 0, False),
                                                        (15, 1, 1, True), (1, 12, 0, True), (5, 47, 0, True), (17, 36, 5, True),
-                                                       (11, 23, 9, True), (63, 20, 2, False)])
+                                                       (11, 23, 9, True), (63, 20, 2, False),
+                                                       (35, 55, 0, True), (21, 66, 3, False), (15, 48, 0, True)])     # round 3: 49..64 disparities
 def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consistent, ss, golden_inputs):
     """asw_aggregate_wave_kernel (small disparity ranges: a wave builds the support weights of its own strip, no
     workgroup barriers) accumulates the same taps in the same order as the workgroup kernels: with both register tiles
@@ -272,7 +273,7 @@ def test_asw_wave_kernel_equals_the_workgroup_kernels(win, maxd, mind, consisten
             _native.set_option(k, None)
 
 
-@pytest.mark.parametrize("maxd,win", [(7, 35), (16, 35), (39, 21)])
+@pytest.mark.parametrize("maxd,win", [(7, 35), (16, 35), (39, 21), (60, 35)])
 def test_asw_wave_kernel_full_width_rows(maxd, win, ss):
     """1920-column rows (20 strips of 96 columns / 15 of 128 / 34 of 56 plus a ragged last one; waves per workgroup 1, 2
     and 4): both tiles of the wave kernel give the map of the workgroup kernels bit for bit"""
@@ -381,7 +382,8 @@ def test_autotune_changes_the_geometry_never_the_map(ss, golden_inputs):
     assert all(w.shape == (96, 128) for w in want)
 
 
-@pytest.mark.parametrize("shape,win,maxd,consistent", [((48, 200), 35, 60, False), ((40, 300), 21, 16, True), ((30, 2000), 35, 192, False)])
+@pytest.mark.parametrize("shape,win,maxd,consistent", [((48, 200), 35, 60, False), ((48, 200), 35, 70, True), ((40, 300), 21, 16, True),
+                                                       ((30, 2000), 35, 192, False)])
 def test_asw_without_room_for_the_tad_volume(shape, win, maxd, consistent, ss):
     """when the device has no room for the pre-computed TAD volume (here: the cap forced down to 1 MiB) the phase-shifted
     kernel builds its e tiles itself and a small range falls back from the wave kernel to the workgroup kernels: same maps"""

@@ -27,7 +27,7 @@ while time.time() < t_end:
         W = int(rng.integers(1800, 2100))
         H = int(rng.integers(1, 30))
     win = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 21, 27, 35, 41, 63]))
-    nD = int(rng.integers(1, 49))
+    nD = int(rng.integers(1, 65))
     mind = int(rng.choice([0, 0, 0, 1, 3, 17]))
     maxd = mind + nD - 1
     cons = bool(rng.random() < 0.5)
