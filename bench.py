@@ -18,7 +18,7 @@ isend/irecv), runs the kernels on its strip and all-gathers the int16 strips.
 
 Rank 0 prints ONE JSON line.  metric = disparity MPixels/s = H*W*nD / t / 1e6
 (nD = maxDisparity - minDisparity + 1), whole job.  Extra objects:
-  roofline      the dominant kernel (asw_aggregate_kernel) against the bound that BINDS it:
+  roofline      the dominant kernel (asw_aggregate_pipe_kernel at the headline configuration) against the bound that BINDS it:
                 fp32 VALU issue.  achieved = exact window taps of the launch x 3 lane-ops per
                 tap (the irreducible v_mul_f32 w = wL*wR, v_fma_f32 N += w*e, v_fma_f32
                 S' += w*(40-e)) / kernel time measured live with HIP events on the launch

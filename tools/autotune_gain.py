@@ -14,7 +14,8 @@ def run(m, tL, tR, n=4):
         best = min(best, (time.perf_counter() - t) * 1e3)
     return best
 
-for (H, W, win, ds) in [(1080, 1920, 35, (7, 16, 24, 32, 40, 47, 55, 64, 96, 192)), (480, 640, 35, (16, 32, 64)), (288, 384, 15, (16,)), (720, 1280, 21, (32, 64, 128))]:
+for (H, W, win, ds) in [(1080, 1920, 35, (7, 16, 24, 32, 40, 47, 55, 64, 80, 96, 128, 160, 192)), (1080, 1920, 21, (16, 64, 128, 192)), (1080, 1920, 11, (16, 64, 192)),
+                        (480, 640, 35, (16, 32, 64)), (288, 384, 15, (16,)), (720, 1280, 21, (32, 64, 128)), (2160, 4096, 35, (256,))]:
     for maxd in ds:
         L, R, _ = make_pair(H, W, maxd, 1)
         tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
