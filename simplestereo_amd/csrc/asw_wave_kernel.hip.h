@@ -18,7 +18,7 @@
 // wait for each other (a workgroup is just four independent waves), and a wave needs ~13 KB of LDS (pixel row,
 // centre pixels, e rows, one weight row), so twelve waves per CU stay resident at 163 VGPRs.
 // e tiles come from the TAD volume of asw_tad_volume_kernel (LDS-DMA, one image row at a time).
-// Used when the whole range fits one chunk of at most 8 disparity groups (nD <= 32).
+// Used when the whole range fits one chunk of at most 16 disparity groups (nD <= 64 since round 3; 48 in round 2).
 #pragma once
 #include "asw_kernels.hip.h"
 #include <type_traits>
