@@ -39,7 +39,7 @@ __device__ __forceinline__ float asw_alt_weight(const PixRec tap, const PixRec c
 {
     const float dL = tap.L - cen.L, da = tap.a - cen.a, db = tap.b - cen.b;
     const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
-    return prox * __builtin_amdgcn_exp2f(dist * kC);
+    return asw_weight_finish(dist, kC, prox);
 }
 
 __device__ __forceinline__ float asw_alt_wave_sum(float v)

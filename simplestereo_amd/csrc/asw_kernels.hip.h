@@ -362,11 +362,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
 #pragma unroll
                         for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
 #pragma unroll
-                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = asw_weight_finish(wv[u], A.kC, pr[u]);
 #pragma unroll
                         for (int u = 0; u < ASW_WB; ++u) {
                             const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
-                            wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                            wp[u * stride] = __uint_as_float(__float_as_uint(wv[u]) & m);
                         }
                     }
                     if (j < j1) {
@@ -386,12 +386,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
 #pragma unroll
                         for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
 #pragma unroll
-                        for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+                        for (int u = 0; u < ASW_WB; ++u) wv[u] = asw_weight_finish(wv[u], A.kC, pr[u]);
 #pragma unroll
                         for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
                             const int jj = min(j + u, j1 - 1);
                             const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
-                            wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                            wout[jj * stride] = __uint_as_float(__float_as_uint(wv[u]) & m);
                         }
                     }
                 }

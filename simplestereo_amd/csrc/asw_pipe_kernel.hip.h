@@ -298,14 +298,14 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
 #pragma unroll
                 for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
 #pragma unroll
-                for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+                for (int u = 0; u < ASW_WB; ++u) wv[u] = asw_weight_finish(wv[u], A.kC, pr[u]);
 #pragma unroll
                 for (int u = 0; u < ASW_WB; ++u) {
                     if constexpr (SSAMD_PIPE_SENTINEL) {
-                        wp[u * stride] = pr[u] * wv[u];
+                        wp[u * stride] = wv[u];
                     } else {
                         const uint32_t m = (unsigned)(col + u) < (unsigned)W ? cmask : 0u;
-                        wp[u * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                        wp[u * stride] = __uint_as_float(__float_as_uint(wv[u]) & m);
                     }
                 }
             }
@@ -327,15 +327,15 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
 #pragma unroll
                 for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_sqrtf(wv[u]);
 #pragma unroll
-                for (int u = 0; u < ASW_WB; ++u) wv[u] = __builtin_amdgcn_exp2f(wv[u] * A.kC);
+                for (int u = 0; u < ASW_WB; ++u) wv[u] = asw_weight_finish(wv[u], A.kC, pr[u]);
 #pragma unroll
                 for (int u = 0; u < ASW_WB; ++u) {  // past the segment end the clamped tap is simply rewritten
                     const int jj = min(j + u, je_t - 1);
                     if constexpr (SSAMD_PIPE_SENTINEL) {
-                        wout[jj * stride] = pr[u] * wv[u];
+                        wout[jj * stride] = wv[u];
                     } else {
                         const uint32_t m = (unsigned)(col0 + jj) < (unsigned)W ? cmask : 0u;
-                        wout[jj * stride] = __uint_as_float(__float_as_uint(pr[u] * wv[u]) & m);
+                        wout[jj * stride] = __uint_as_float(__float_as_uint(wv[u]) & m);
                     }
                 }
             }

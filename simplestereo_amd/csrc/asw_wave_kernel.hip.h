@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
     auto weight = [&](const float4 &ce, const float4 &tp, float pj) {
         const float dL = tp.x - ce.x, da = tp.y - ce.y, db = tp.z - ce.z;
         const float dist = __builtin_amdgcn_sqrtf(fmaf(db, db, fmaf(da, da, dL * dL)));
-        return pj * __builtin_amdgcn_exp2f(dist * A.kC);
+        return asw_weight_finish(dist, A.kC, pj);
     };
     // Two tap columns (j, j + 1) per build: a centre is read once for both, and the wave pays the LDS round trip of a
     // build once per two aggregation steps.  Weight row q = column parity, at wS + q * wrow.

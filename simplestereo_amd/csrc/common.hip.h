@@ -14,6 +14,22 @@ struct __attribute__((aligned(16))) PixRec {
     uint32_t bgrx;
 };
 
+// The last two operations of an ASW support weight (_passive.cpp:47-50, 71-74): proximity weight x exp(-colour distance / gammaC).
+// SSAMD_W_FOLD=1 (experiment, tools/build_variants.sh): the proximity table holds log2 of the weights and the product becomes
+// one fused multiply-add in the exponent -- one VALU instruction less per weight, the same result to within an ulp of the
+// exponent.  Every ASW kernel goes through this one function, so they stay bit-identical to each other either way.
+#ifndef SSAMD_W_FOLD
+#define SSAMD_W_FOLD 0
+#endif
+__device__ __forceinline__ float asw_weight_finish(float dist, float kC, float prox)
+{
+#if SSAMD_W_FOLD
+    return __builtin_amdgcn_exp2f(fmaf(dist, kC, prox));
+#else
+    return prox * __builtin_amdgcn_exp2f(dist * kC);
+#endif
+}
+
 typedef unsigned long long u64;
 static constexpr u64 KEY_NONE = ~0ull;
 

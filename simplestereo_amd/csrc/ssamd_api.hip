@@ -769,7 +769,11 @@ int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
     for (int i = 0; i < win; ++i)
         for (int j = 0; j < win; ++j) {
             const double di = i - p, dj = j - p;
+#if SSAMD_W_FOLD
+            e.host[(size_t)i * win + j] = (float)(-std::sqrt(di * di + dj * dj) / gammaP * 1.4426950408889634);      // log2 of the weight
+#else
             e.host[(size_t)i * win + j] = (float)std::exp(-std::sqrt(di * di + dj * dj) / gammaP);
+#endif
         }
     int rc = e.dev.reserve(e.host.size() * 4);
     if (rc) { c.proxTabs.entries.pop_front(); return rc; }
