@@ -58,7 +58,7 @@ namespace ssamd {
 static constexpr int TADV_COLS = 64;
 __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__restrict__ recL, const PixRec *__restrict__ recR,
                                                              unsigned char *__restrict__ evol, int W, int pad, int minD, int Dc,
-                                                             int Se, int erow0, int erows, int evolW)
+                                                             int Se, int erow0, int erows, int evolW, int rd = 4)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *const sL = reinterpret_cast<uint32_t *>(smem);                 // [TADV_COLS]
@@ -77,14 +77,17 @@ __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__res
     __syncthreads();
     const int ncols = min(TADV_COLS, evolW - uc0);
     uint32_t *const out = reinterpret_cast<uint32_t *>(evol + (((size_t)z * erows + blockIdx.y) * (size_t)evolW + uc0) * Se);
-    auto dword = [&](int c, int slot, uint32_t lp) {             // the four disparities dlo + 4 slot + 0..3 of column c
+    // rd = 4: dword `slot` of a column holds the disparities dlo + 4 slot + 0..3;  rd = 6 (asw_wave6_kernel.hip.h): a
+    // disparity group is an 8-byte slot, dword 2 g holds dlo + 6 g + 0..3 and dword 2 g + 1 holds dlo + 6 g + 4, 5
+    auto dword = [&](int c, int slot, uint32_t lp) {
         uint32_t v = 0;
-        if (!(lp >> 31) && 4 * slot < Dc) {
-            // R[u - d] for d = dlo + 4 slot + q  ->  staged index c + (Dc - 1) - 4 slot - q
-            const uint32_t *const rp = sR + c + (Dc - 1) - 4 * slot;
+        const int d0 = rd == 6 ? 6 * (slot >> 1) + 4 * (slot & 1) : 4 * slot, nv = rd == 6 && (slot & 1) ? 2 : 4;
+        if (!(lp >> 31) && d0 < Dc) {
+            // R[u - d] for d = dlo + d0 + q  ->  staged index c + (Dc - 1) - d0 - q
+            const uint32_t *const rp = sR + c + (Dc - 1) - d0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t rv = 4 * slot + q < Dc ? rp[-q] : 0x80000000u;
+                const uint32_t rv = q < nv && d0 + q < Dc ? rp[-q] : 0x80000000u;
                 if (!(rv >> 31)) v |= min(__builtin_amdgcn_sad_u8(lp, rv, 0u), 40u) << (8 * q);
             }
         }

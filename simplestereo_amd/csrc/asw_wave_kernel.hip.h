@@ -31,6 +31,7 @@ struct AswWaveGeom {
     int SLw, SRw, Se;                       // floats per weight row (left / right part), bytes per e column
     int waves;                              // waves per workgroup
     int merged, K;                          // round 3: left and right centres in ONE list of K = ceil((Txw + nRcw) / 64) build rounds
+    int RD;                                 // disparities per lane: 4, or 6 (asw_wave6_kernel.hip.h: 8-byte e slots, Se = 8 * odd)
     int off_w, off_cen, off_pixL, off_pixR, off_e, off_bestL, off_bestR;     // offsets inside a wave's LDS slice
     int wave_lds;                           // bytes of LDS per wave
 };

@@ -22,6 +22,7 @@
 #include "asw_kernels.hip.h"
 #include "asw_pipe_kernel.hip.h"
 #include "asw_wave_kernel.hip.h"
+#include "asw_wave6_kernel.hip.h"
 #include "asw_alt_kernels.hip.h"
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
@@ -63,6 +64,7 @@ struct Tuning {
     int wave_merge = 1;               // 0: left and right centres of a strip in separate build rounds (round-2 form)
     int asw_static = 1;               // 0: the phase-shifted kernel always reads its strides from the geometry (round-2 form)
     int evol_max_mb = 0;              // 0 unset; else a cap of the TAD volume in MiB (tests of the paths taken when memory is short)
+    int wave_rd = 0;                  // 0: the host decides; 4: never the six-disparities-per-lane form of the wave kernel
     bool no_e2 = false, xor_only = false, multi_allow_repeat = false;
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
@@ -85,6 +87,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_WAVE_MERGE") t.wave_merge = num(1);
     else if (name == "SSAMD_ASW_STATIC") t.asw_static = num(1);
     else if (name == "SSAMD_ASW_EVOL_MAX_MB") t.evol_max_mb = v ? std::max(0, atoi(v)) : 0;
+    else if (name == "SSAMD_ASW_WAVE_RD") t.wave_rd = num(0);
     else if (name == "SSAMD_ASW_NO_E2") t.no_e2 = v != nullptr;
     else if (name == "SSAMD_ASW_XOR_ONLY") t.xor_only = v != nullptr;
     else if (name == "SSAMD_MULTI_ALLOW_REPEAT") t.multi_allow_repeat = v != nullptr;
@@ -96,7 +99,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
-                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
+                                    "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
                                     "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE"};
 
 Tuning tuning_from_env()
@@ -474,14 +477,15 @@ void asw_try_pipe(AswGeom &g, int win)
 // slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
 static constexpr int ASW_WAVE_MAX_DG = 16;
 // One candidate strip: nxg column groups, left / right centres in separate build rounds or merged into one list.
-bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool merged)
+bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool merged, int rd = ASW_RD)
 {
     g.RX = rx;
+    g.RD = rd;
     const int p = win / 2;
     g.DG = DG;
     g.NXG = nxg;
     g.Txw = rx * g.NXG;
-    g.Dc = ASW_RD * g.DG;
+    g.Dc = rd * g.DG;
     g.lanes = g.NXG * g.DG;
     g.nLw = g.Txw + 2 * p;
     g.nRcw = g.Txw + g.Dc - 1;
@@ -500,7 +504,7 @@ bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool 
     // bytes per e column: an odd number of dwords, so that the e dwords the lanes of a wave read in one step (column
     // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
     // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
-    g.Se = 4 * (g.DG | 1);
+    g.Se = rd == 6 ? 8 * ((g.DG + 1) | 1) : 4 * (g.DG | 1);        // (six per lane: 8-byte slots, an odd number of them and one to spare)
     g.waves = tune().wave_wg ? tune().wave_wg : 1;
     // order matters: the build's last round reads up to 127 entries past the end of the centres and of each pixel
     // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile -- and the merged build
@@ -524,8 +528,11 @@ bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool 
 // whether the left and right centres are built as one list are chosen by the cost per column of a tap column's work,
 // K build rounds (~17 issue slots each: one weight per lane) + the taps (~59 slots with the 4-column tile, ~110 with
 // the 8-column one).  SSAMD_ASW_WAVE_MERGE=0 restores the round-2 form (all column groups, separate rounds).
+// rx: 8 or 4 columns per lane; 4 | 16 (= 20, an autotuning candidate, AswGeom::wave_rx): 4 columns and never six disparities per lane
 bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
 {
+    const bool never6 = (rx & 16) != 0;
+    rx &= 15;
     const int DG = (nD + ASW_RD - 1) / ASW_RD;
     if (DG < 1 || DG > ASW_WAVE_MAX_DG) return false;
     const int nxg_max = 64 / DG;
@@ -546,6 +553,21 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
             const double cost = (c.K * c_round + c_taps) / (double)c.Txw;
             if (cost < best - 1e-9) { best = cost; g = c; found = true; }
         }
+    // Six disparities per lane (asw_wave6_kernel.hip.h, 4-column tile, merged rounds only): where the range pads badly to groups of
+    // four -- 17 and 18 disparities, the class default among them: three groups of six, 21 column groups, three build rounds
+    // for 84 columns -- it must beat the four-per-lane strip by 5 % of the modelled cost to be taken
+    if (found && rx == 4 && !never6 && tune().wave_rd != 4 && tune().wave_merge != 0) {
+        const int DG6 = (nD + 5) / 6;
+        if (DG6 >= 1 && DG6 <= 10) {
+            const int nxg6 = 64 / DG6;
+            for (int nxg = nxg6; nxg >= std::max(1, nxg6 - 4); --nxg) {
+                AswWaveGeom c;
+                if (!asw_wave_layout_one(c, win, DG6, 4, nxg, true, 6) || c.K > 4) continue;
+                const double cost = (c.K * c_round + 87.0) / (double)c.Txw;
+                if (cost < 0.95 * best) { best = cost / 0.95; g = c; }
+            }
+        }
+    }
     return found;
 }
 
@@ -601,7 +623,7 @@ bool asw_geometry_forced()
 {
     const Tuning &t = tune();
     return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
-           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0;
+           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0 || t.wave_rd != 0;
 }
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
@@ -735,6 +757,11 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             if (!tune().wave_rx && asw_wave_layout(wg, win, nD, 12 - wave_rx)) {
                 AswGeom other = best;
                 other.wave_rx = 12 - wave_rx;
+                shortlist->push_back(other);
+            }
+            if (wave_rx == 4 && asw_wave_layout(wg, win, nD, 4) && wg.RD == 6) {      // ... and the four-per-lane strip next to the six-per-lane one
+                AswGeom other = best;
+                other.wave_rx = 4 | 16;
                 shortlist->push_back(other);
             }
         }
@@ -935,7 +962,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), (unsigned)chunks);
             const size_t elds = (size_t)(2 * TADV_COLS + Dc) * 4;
             hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), elds, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
-                               (unsigned char *)c.evol.ptr, W, p, minD, Dc, Se, r0, r1 - r0, evolW);
+                               (unsigned char *)c.evol.ptr, W, p, minD, Dc, Se, r0, r1 - r0, evolW, g.wave_rx ? wa.g.RD : 4);
             HIP_TRY(hipGetLastError());
             return SSAMD_OK;
         };
@@ -954,7 +981,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 // build rounds known at compile time (straight-line build): the common combinations
                 const int kl = (wa.g.Txw + 63) / 64, kr = (wa.g.nRcw + 63) / 64;
                 const bool unrolled = tune().wave_unroll != 0;
-                if (unrolled && !d_costs && wa.g.merged) {
+                if (wa.g.RD == 6) {                                                         // six disparities per lane
+                    wk = d_costs ? asw_aggregate_wave6_kernel<true, 0> : asw_aggregate_wave6_kernel<false, 0>;
+                    if (unrolled && !d_costs && wa.g.K == 3) wk = asw_aggregate_wave6_kernel<false, 3>;
+                    else if (unrolled && !d_costs && wa.g.K == 2) wk = asw_aggregate_wave6_kernel<false, 2>;
+                } else if (unrolled && !d_costs && wa.g.merged) {
                     const int key = wa.g.RX * 10 + wa.g.K;                                  // merged build, K rounds
                     if (key == 42) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 2>;        // class default D 0..16: 48 + 67 centres
                     else if (key == 43) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 3>;
@@ -1487,8 +1518,8 @@ int ssamd_asw_kernel_form(int width, int rows, int winSize, int maxDisparity, in
     AswGeom g;
     if ((rc = asw_choose_geometry(g, width, rows, winSize, nD))) return rc;
     out[0] = g.pipe; out[1] = g.Rx; out[2] = g.JC >= winSize ? 0 : g.JC; out[3] = g.pipe ? g.dephase : 0;
-    out[4] = g.wave_rx;
-    if (g.wave_rx) { out[0] = 0; out[1] = g.wave_rx; out[2] = 0; out[3] = 0; }
+    out[4] = g.wave_rx & 15;
+    if (g.wave_rx) { out[0] = 0; out[1] = g.wave_rx & 15; out[2] = 0; out[3] = 0; }
     return SSAMD_OK;
 }
 

@@ -398,3 +398,43 @@ def test_asw_without_room_for_the_tad_volume(shape, win, maxd, consistent, ss):
         got = m.compute(tL, tR)
     assert torch.equal(got, want)
     assert torch.equal(m.compute(tL, tR), want)
+
+
+@pytest.mark.parametrize("win,maxd,mind,consistent", [(35, 16, 0, False), (35, 16, 0, True), (15, 17, 0, True), (7, 21, 5, False), (63, 18, 2, True),
+                                                       (11, 22, 5, True)])
+def test_asw_wave_kernel_six_disparities_per_lane(win, maxd, mind, consistent, ss, golden_inputs):
+    """asw_aggregate_wave6_kernel (17 / 18 disparities -- the class default maxDisparity = 16 -- as three groups of SIX per
+    lane: 8-byte e slots, nine right weights from an 8-byte-aligned address) computes the maps and the raw costs of the
+    four-per-lane wave kernel and of the workgroup kernels bit for bit, on full and ragged images"""
+    from simplestereo_amd.synth import make_pair
+    nD = maxd - mind + 1
+    assert nD in (17, 18)
+    a, b = golden_inputs("synth_96x128")
+    L2, R2, _ = make_pair(37, 700, maxd, 5)
+    pairs = [(a, b), (np.ascontiguousarray(a[:50, :77]), np.ascontiguousarray(b[:50, :77])), (L2, R2),
+             (np.ascontiguousarray(a[:9, :23]), np.ascontiguousarray(b[:9, :23]))]
+    m = ss.passive.StereoASW(winSize=win, maxDisparity=maxd, minDisparity=mind, consistent=consistent, gammaC=6.0)
+
+    def run(L, R):
+        H, W = L.shape[:2]
+        c = np.empty((H, W, nD), np.float32)
+        _native.check(_native.lib().ssamd_asw_costs(L.ctypes.data, R.ctypes.data, H, W, win, maxd, mind, 6.0, 17.5, c.ctypes.data, -1))
+        return m.compute(L, R), c
+    try:
+        _native.set_option("SSAMD_ASW_WAVE", "0")
+        want = [run(L, R) for L, R in pairs]
+        _native.set_option("SSAMD_ASW_WAVE", "1")
+        _native.set_option("SSAMD_ASW_WAVE_RX", "4")
+        if _native.asw_kernel_form(700, 37, win, maxd, mind)["wave_kernel"] != 4:
+            pytest.skip("the 4-column tile does not fit LDS for this window")
+        assert _native.asw_geometry(700, 37, win, maxd, mind)["chunk_d"] == 18          # three groups of six
+        six = [run(L, R) for L, R in pairs]
+        _native.set_option("SSAMD_ASW_WAVE_RD", "4")
+        assert _native.asw_geometry(700, 37, win, maxd, mind)["chunk_d"] == 20          # five groups of four
+        four = [run(L, R) for L, R in pairs]
+        for (wd, wc), (sd, sc), (fd, fc) in zip(want, six, four):
+            assert np.array_equal(sd, wd) and np.array_equal(fd, wd)
+            assert np.array_equal(sc, wc, equal_nan=True) and np.array_equal(fc, wc, equal_nan=True)
+    finally:
+        for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_RD"):
+            _native.set_option(k, None)

@@ -20,14 +20,14 @@ rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
 lib = _native.lib()
 t_end = time.time() + budget
 n = skipped = 0
-HOOKS = ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL", "SSAMD_ASW_WAVE_MERGE")
+HOOKS = ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL", "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_WAVE_RD")
 while time.time() < t_end:
     H, W = int(rng.integers(1, 140)), int(rng.integers(1, 700))
     if rng.random() < 0.1:
         W = int(rng.integers(1800, 2100))
         H = int(rng.integers(1, 30))
     win = int(rng.choice([1, 3, 5, 7, 9, 11, 15, 21, 27, 35, 41, 63]))
-    nD = int(rng.integers(1, 65))
+    nD = int(rng.integers(1, 65)) if rng.random() < 0.8 else int(rng.choice([17, 18]))
     mind = int(rng.choice([0, 0, 0, 1, 3, 17]))
     maxd = mind + nD - 1
     cons = bool(rng.random() < 0.5)
@@ -53,6 +53,7 @@ while time.time() < t_end:
         _native.set_option("SSAMD_ASW_WAVE_WG", wg_)
         _native.set_option("SSAMD_ASW_WAVE_UNROLL", unroll_)
         _native.set_option("SSAMD_ASW_WAVE_MERGE", None if rng.random() < 0.7 else "0")      # round 3: merged build rounds (default) / separate
+        _native.set_option("SSAMD_ASW_WAVE_RD", None if rng.random() < 0.7 else "4")         # six disparities per lane where the host takes them / never
         if _native.asw_kernel_form(W, H, win, maxd, mind)["wave_kernel"] != int(rx):
             skipped += 1
             continue
