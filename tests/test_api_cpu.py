@@ -153,7 +153,7 @@ def test_geometry_query_is_sane(ss):
     for (W, win, maxd, mind) in [(1920, 35, 192, 0), (640, 35, 64, 0), (384, 15, 16, 0), (4096, 35, 256, 0), (40, 7, 6, 1), (64, 255, 3, 0)]:
         g = _native.asw_geometry(W, 10, win, maxd, mind)
         nD = maxd - mind + 1
-        assert g["tile_x"] % 4 == 0 and g["chunk_d"] % 4 == 0        # 8- or 4-column register tiles x 4 disparities
+        assert g["tile_x"] % 4 == 0 and (g["chunk_d"] % 4 == 0 or g["chunk_d"] % 6 == 0)        # 8- or 4-column register tiles x 4 (or 6: wave6) disparities
         assert g["chunk_d"] * g["n_chunks"] >= nD and g["chunk_d"] * (g["n_chunks"] - 1) < nD
         assert g["threads"] % 64 == 0 and 64 <= g["threads"] <= 768
         assert g["lds_bytes"] <= 160 * 1024
