@@ -97,3 +97,31 @@ def test_bench_forced_distributed_line_at_world_1():
     plain = json.loads([l for l in r2.stdout.splitlines() if l.strip()][-1])
     assert plain["config"]["checksum"] == line["config"]["checksum"]
     assert "rccl" not in plain
+
+
+def test_bench_line_carries_the_contract_keys():
+    """the line the driver parses: metric / value / unit / steps, `roofline` {bound, achieved, peak, unit, frac, traffic},
+    `cpu_baseline` {value, unit, cores, kind, sample}, the accuracy figure on the reference's strips -- on a small
+    configuration with a tiny CPU sample so that the test stays short"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SSAMD_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--config", "c2_480p_d64_w35",
+                        "--no-others", "--no-e2e", "--cpu-crop-cols", "96"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "bad1_vs_cpu_ref"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["value"] > 0 and abs(line["value"] - 480 * 640 * 65 / (line["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * line["value"]
+    assert "workload" in line["config"] and line["dtype"] == "f32" and line["data"] == "synthetic"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel_ms"] <= line["ms_per_step"] * 1.02
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
+    assert line["bad1_vs_cpu_ref"]["percent"] <= 0.5
