@@ -159,3 +159,20 @@ def test_reference_module_agrees_when_present(golden_cases, golden_inputs):
     a, b = golden_inputs("crop")
     d = ref.computeASW(a, b, 7, 6, 1, 5.0, 17.5, True)
     assert np.array_equal(d, maps["G5c"])
+
+
+@pytest.mark.parametrize("cid", ["P1", "P1c", "P2a", "P3b", "P4a", "P4b"])
+def test_oracle_on_photographs(cid):
+    """the C restatement (hoisted / closed-form modes) against the reference's maps of REAL PHOTOGRAPHS -- the lawn pair of the
+    reference's own ASW example (examples/009) at quarter size with the example's parameters and as a full-width native strip
+    with D 4..100, an unrectified capture for GSW (tests/golden/make_golden_photo.py) -- bit-exact.  (P2b / P3a, consistent at
+    full width, are checked on the GPU tier only: the oracle needs a minute for them.)"""
+    m = json.load(open(os.path.join(GOLDEN, "photo_cases.json")))[cid]
+    want = np.load(os.path.join(GOLDEN, "photo_cases.npz"))[cid]
+    pairs = np.load(os.path.join(GOLDEN, "photo_pairs.npz"))
+    a, b = np.ascontiguousarray(pairs[m["pair"] + "_L"]), np.ascontiguousarray(pairs[m["pair"] + "_R"])
+    assert hashlib.sha256(a.tobytes() + b.tobytes()).hexdigest() == m["input_sha256"]
+    assert hashlib.sha256(want.tobytes()).hexdigest() == m["sha256"]
+    p = {k: v for k, v in m["params"].items() if k != "algo"}
+    got = oracle.asw(a, b, hoist=True, **p) if m["params"]["algo"] == "asw" else oracle.gsw(a, b, closed=True, **p)
+    assert np.array_equal(got, want)
