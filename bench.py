@@ -102,7 +102,7 @@ def count_taps(H, W, win, maxD, minD, row0=0, rows=None):
     return int(vrows.sum()) * int(cols.sum())
 
 
-def cpu_baseline(cfg, seed, rows_per_thread=1, timeout_s=900, crop_cols=512):
+def cpu_baseline(cfg, seed, rows_per_thread=1, timeout_s=900, crop_cols=512, repeats=2):
     """Time the reference (and the hoisted plain-C port) on a bounded crop of the same frame, on the host cores.
 
     The reference hands out ONE image row per job to hardware_concurrency() threads (_passive.cpp:352-355, 372-396),
@@ -168,7 +168,18 @@ print(json.dumps({"t": dt, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}
                           "exact tap count" %
                           (cols, rows, rows, rows / float(res["cores"]), cols, W, taps / full, float(full), res["t"], res["cores"])}
     try:
-        cb = entry(run(rows, "reference", dump))
+        # the denominator is noisy on these hosts (0.69-1.5 MP*disp/s for the same code across boxes and rounds: 256 SMT
+        # threads, whatever else the host runs): the sample is timed `repeats` times and the spread reported
+        load0 = os.getloadavg()
+        runs = [entry(run(rows, "reference", dump)) for _ in range(max(1, repeats))]
+        cb = dict(runs[0])
+        vals = [r["value"] for r in runs]
+        cb["value"] = sum(vals) / len(vals)
+        cb["value_min"], cb["value_max"] = min(vals), max(vals)
+        cb["runs"] = [{"value": r["value"], "wall_s": r["wall_s"]} for r in runs]
+        cb["wall_s"] = sum(r["wall_s"] for r in runs)
+        cb["host_loadavg_before"], cb["host_loadavg_after"] = list(load0), list(os.getloadavg())
+        cb["sample"] += "; timed %d times, value = mean, value_min / value_max = the spread" % len(runs)
         cb["map_file"] = dump
     except Exception as e:      # noqa: BLE001  -- the baseline must never sink the bench line
         return {"value": None, "unit": "MPixels*disp/s", "cores": cores, "kind": "unavailable", "sample": repr(e)[:200]}
@@ -184,6 +195,37 @@ print(json.dumps({"t": dt, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}
     except Exception as e:      # noqa: BLE001
         cb["hoisted"] = {"value": None, "kind": "unavailable", "sample": repr(e)[:200]}
     return cb
+
+
+WEIGHT_OPS = 12     # lane-ops per support weight (3 sub, mul, 2 fma, sqrt, mul, exp2, mul + addressing)
+
+
+def weight_lane_ops(H, W, win, rows=None):
+    """algorithmic lane-ops of the support-weight construction: one weight per (pixel, window cell) and image"""
+    return WEIGHT_OPS * 2 * (H if rows is None else rows) * W * win * win
+
+
+def replayed_issue(config_name, k_ms):
+    """VALU instruction count of a committed rocprofv3 PMC pass of this configuration (profiles/valu_<config>.json)
+    related to this run's kernel time: issued / useful and the issue rate per SIMD.  None when no pass is committed."""
+    vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % config_name)
+    if not (os.path.exists(vpath) and k_ms):
+        return None
+    try:
+        vj = json.load(open(vpath))
+        n = vj["SQ_INSTS_VALU_per_launch"]
+        rate = n / (k_ms * 1e-3) / 1024 / 1e9          # 256 CUs x 4 SIMDs
+        out = {"wave_instructions_per_launch": n, "achieved_G_wave_instr_per_s_per_simd": rate,
+               "plain_fp32_peak_G_wave_instr_per_s_per_simd": vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"],
+               "frac": rate / vj["plain_fp32_issue_peak_G_wave_instr_per_s_per_simd"],
+               "source": "profiles/valu_%s.json (builder rocprofv3 --pmc SQ_INSTS_VALU run of this configuration, kernel %s); "
+                         "the kernel time it is divided by is this run's" % (config_name, vj.get("kernel", "?"))}
+        if vj.get("useful_lane_ops_per_launch"):
+            out["issued_over_useful_lane_ops"] = 64.0 * n / vj["useful_lane_ops_per_launch"]
+            out["useful_definition"] = vj.get("useful_definition")
+        return out
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def replayed_counters(config_name, k_ms):
@@ -272,10 +314,16 @@ def others(dev, seed):
             wall, k_ms, checksum = time_matcher(m, tL, tR, _native.K_ASW_AGG)
             taps = count_taps(H, W, win, maxD, minD)
             nD = maxD - minD + 1
+            wops = weight_lane_ops(H, W, win)
             res[name] = {"matcher": "StereoASW", "H": H, "W": W, "maxDisparity": maxD, "minDisparity": minD, "winSize": win,
                          "consistent": consistent, "ms_per_step": wall, "value": H * W * nD / (wall * 1e-3) / 1e6,
                          "unit": "MPixels*disp/s", "kernel_ms": k_ms, "taps": taps, "checksum": checksum,
                          "valu_frac": VALU_OPS_PER_TAP * taps / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None,
+                         # SURVEY 8d also counts the support-weight construction (2 H W win^2 weights x ~12 lane-ops): the larger
+                         # share of the work for small disparity ranges, ~1.5 % at D 0..192
+                         "weight_lane_ops": wops,
+                         "valu_frac_with_weights": (VALU_OPS_PER_TAP * taps + wops) / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None,
+                         "issue": replayed_issue(cfgname, k_ms) if not consistent else None,
                          "kernel_form": _native.asw_kernel_form(W, H, win, maxD, minD)}
         except Exception as e:      # noqa: BLE001
             res[name] = {"error": repr(e)[:200]}
@@ -296,6 +344,7 @@ def others(dev, seed):
                                       "taps": taps, "lane_ops_per_tap": GSW_OPS_PER_TAP, "tap_instructions": GSW_TAP_INSTRUCTIONS,
                                       "achieved": achieved, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
                                       "frac": achieved / VALU_PEAK_LANEOPS if achieved else None,
+                                      "issue": replayed_issue(name, k_ms),
                                       "hbm": {"algorithmic_bytes_per_step": GSW_ALGO_BYTES_PER_PIXEL * H * W,
                                               "frac": GSW_ALGO_BYTES_PER_PIXEL * H * W / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else None}}}
         except Exception as e:      # noqa: BLE001
@@ -303,32 +352,58 @@ def others(dev, seed):
     return res
 
 
-def bad1_on_reference_strips(dev):
-    """GPU maps of the committed full-width reference strips (tests/golden/wide_cases.*, generated by the unmodified
-    reference through tests/golden/make_golden_wide.py) against the reference's maps: 0 s of CPU time."""
+def bad1_on_reference_strips(dev, rank=0, world=1):
+    """GPU maps of the committed full-width reference strips (tests/golden/wide_cases.*: the config-3 frames; and
+    tests/golden/photo_cases.*: the lawn pair of the reference's own ASW example at native width, D 4..100) against the
+    maps of the unmodified reference: 0 s of CPU time.  With world > 1 every case goes through a StripContext over all
+    ranks (row strips + RCCL halo exchange + all-gather, the path the timed region ran) -- every rank must call this;
+    rank 0 gets the figures."""
     import numpy as np
+    import torch
     import simplestereo_amd as ss
+    from simplestereo_amd import strips
     from simplestereo_amd.synth import make_pair
     gdir = os.path.join(ROOT, "tests", "golden")
     maps = np.load(os.path.join(gdir, "wide_cases.npz"))
     meta = json.load(open(os.path.join(gdir, "wide_cases.json")))
+    pmaps = np.load(os.path.join(gdir, "photo_cases.npz"))
+    pmeta = json.load(open(os.path.join(gdir, "photo_cases.json")))
+    ppairs = np.load(os.path.join(gdir, "photo_pairs.npz"))
     cases, bad, exact, pix = {}, 0, 0, 0
-    for cid in ("W3a", "W3b"):
-        m = meta[cid]
-        H, W, maxD, seed = m["frame"]
-        L, R, _ = make_pair(H, W, maxD, seed)
-        a = np.ascontiguousarray(L[m["row0"]:m["row0"] + m["rows"]])
-        b = np.ascontiguousarray(R[m["row0"]:m["row0"] + m["rows"]])
+    for cid in ("W3a", "W3b", "P2a"):
+        if cid.startswith("W"):
+            m = meta[cid]
+            H, W, maxD, seed = m["frame"]
+            L, R, _ = make_pair(H, W, maxD, seed)
+            a = np.ascontiguousarray(L[m["row0"]:m["row0"] + m["rows"]])
+            b = np.ascontiguousarray(R[m["row0"]:m["row0"] + m["rows"]])
+            want, what = maps[cid], m["recipe"]
+        else:
+            m = pmeta[cid]
+            a, b = np.ascontiguousarray(ppairs[m["pair"] + "_L"]), np.ascontiguousarray(ppairs[m["pair"] + "_R"])
+            want, what = pmaps[cid], "photograph: tests/golden/photo_pairs.npz %s (reference examples/res/2 lawn pair, rectified, native width)" % m["pair"]
         p = {k: v for k, v in m["params"].items() if k != "algo"}
-        d = ss.passive.StereoASW(**p).compute(a, b)
-        diff = np.abs(d.astype(np.int32) - maps[cid].astype(np.int32))
+        matcher = ss.passive.StereoASW(**p)
+        if world > 1:
+            rows = a.shape[0]
+            q0, q1 = strips.strip_bounds(rows, world, rank)
+            ctx = strips.StripContext(matcher, rows, a.shape[1], rank, world, dev)
+            d = ctx.step(torch.from_numpy(np.ascontiguousarray(a[q0:q1])).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(b[q0:q1])).to(dev), gather=True).cpu().numpy()
+        else:
+            d = matcher.compute(a, b)
+        diff = np.abs(d.astype(np.int32) - want.astype(np.int32))
         cases[cid] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
-                      "pixels": int(diff.size), "consistent": bool(p["consistent"]), "recipe": m["recipe"]}
-        bad += int(np.count_nonzero(diff > 1)); exact += int(np.count_nonzero(diff == 0)); pix += int(diff.size)
+                      "pixels": int(diff.size), "consistent": bool(p["consistent"]), "maxDisparity": p["maxDisparity"],
+                      "minDisparity": p["minDisparity"], "recipe": what}
+        if cid.startswith("W"):          # the headline figure stays the config-3 geometry; the photograph is reported next to it
+            bad += int(np.count_nonzero(diff > 1)); exact += int(np.count_nonzero(diff == 0)); pix += int(diff.size)
     return {"percent": 100.0 * bad / pix, "exact_percent": 100.0 * exact / pix, "pixels": pix, "cases": cases,
+            "through": "one launch per case" if world == 1 else "StripContext over %d ranks (row strips, RCCL halo exchange, all_gather)" % world,
             "source": "tests/golden/wide_cases.npz W3a + W3b: full-width 1920 x 72 strips of the config-3 frames (seed 0 plain, "
                       "seed 1 = this run's frame with consistent=True), D 0..192, win 35, maps by the unmodified reference "
-                      "(_passive.cpp via oracle/_ref, tests/golden/make_golden_wide.py)"}
+                      "(_passive.cpp via oracle/_ref, tests/golden/make_golden_wide.py); cases.P2a: a real photograph "
+                      "(tests/golden/make_golden_photo.py), not part of `percent`"}
 
 
 def e2e_host_arrays(seed, resident_ms):
@@ -443,6 +518,7 @@ def main():
                     help="cpu_baseline sample height in rows per host thread (the reference schedules one row per job)")
     ap.add_argument("--cpu-crop-cols", type=int, default=512,
                     help="cpu_baseline sample width (centre columns); 0 = full width (minutes of CPU time at 1080p)")
+    ap.add_argument("--cpu-repeats", type=int, default=2, help="how many times the cpu_baseline sample of the reference is timed")
     ap.add_argument("--with-alternate", action="store_true",
                     help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-array (PCIe-inclusive) timings")
@@ -549,9 +625,12 @@ def main():
         # what every rank actually ran on, collected on rank 0
         phases = strip_ctx.read_timing() or {}
         strip_ctx.enable_timing(False)
+        my_k = ms[_native.K_ASW_AGG] / max(1, launches[_native.K_ASW_AGG])
+        my_taps = count_taps(H, W, win, maxD, minD, r0, r1 - r0) if r1 > r0 else 0
         mine = {"rank": rank, "device": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(dev),
                 "strip_rows": [r0, r1], "halo_rows": [strip_ctx.h0, strip_ctx.h1],
-                "kernel_ms": ms[_native.K_ASW_AGG] / max(1, launches[_native.K_ASW_AGG]),
+                "kernel_ms": my_k, "taps": my_taps,
+                "valu_frac": VALU_OPS_PER_TAP * my_taps / (my_k * 1e-3) / VALU_PEAK_LANEOPS if my_k > 0 else None,
                 "halo_exchange_ms": phases.get("exchange_ms"), "kernels_phase_ms": phases.get("kernels_ms"),
                 "gather_ms": phases.get("gather_ms"), "messages_sent": len(strip_ctx.sends), "messages_received": len(strip_ctx.recvs)}
         per_rank = [None] * world
@@ -563,7 +642,17 @@ def main():
             rccl["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:      # noqa: BLE001
             pass
+        ks = [r["kernel_ms"] for r in per_rank if r and r.get("kernel_ms")]
+        if ks:
+            rccl["kernel_ms_min"], rccl["kernel_ms_max"] = min(ks), max(ks)
     checksum = int(out.to(torch.int64).sum().item())
+    bad1_dist = None
+    if world > 1 and not args.no_bad1:
+        # the accuracy half of the metric THROUGH the distributed path (every rank takes part; rank 0 keeps the figures)
+        try:
+            bad1_dist = bad1_on_reference_strips(dev, rank, world)
+        except Exception as e:      # noqa: BLE001
+            bad1_dist = {"percent": None, "source": repr(e)[:200]}
 
     if rank == 0:
         per_step = dt / args.steps
@@ -613,6 +702,22 @@ def main():
         }
         if rccl is not None:
             line["rccl"] = rccl
+        if world > 1:
+            # the slowest rank's strip against the roofline (a step ends when the slowest strip does), and the strips'
+            # map against ONE launch over the whole frame on rank 0's GPU (outside the timed region)
+            slow = max((r for r in rccl["ranks"] if r and r.get("kernel_ms")), key=lambda r: r["kernel_ms"], default=None)
+            if slow is not None:
+                line["roofline"].update({"frac": slow["valu_frac"], "kernel_ms": slow["kernel_ms"], "taps_per_launch": slow["taps"],
+                                         "achieved": VALU_OPS_PER_TAP * slow["taps"] / (slow["kernel_ms"] * 1e-3),
+                                         "of_rank": slow["rank"], "note": "the slowest rank's strip"})
+            try:
+                single = matcher.compute(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev))
+                line["config"]["checksum_single_gpu"] = int(single.to(torch.int64).sum().item())
+                line["config"]["checksum_equals_single_gpu"] = bool(torch.equal(single, out.to(single.device)))
+            except Exception as e:      # noqa: BLE001
+                line["config"]["checksum_equals_single_gpu"] = repr(e)[:160]
+            if bad1_dist is not None:
+                line["bad1_vs_cpu_ref"] = bad1_dist
         if world == 1 and not args.consistent and args.with_alternate:
             # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
             alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
@@ -651,7 +756,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 line["e2e_host_arrays"] = {"error": repr(e)[:200]}
         if world == 1 and not use_dist and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1])
+            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1], repeats=args.cpu_repeats)
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
             # the CPU baseline computed (matched as a stand-alone sub-image by both)
             try:
@@ -695,6 +800,7 @@ def main():
             line["cpu_baseline"] = cb
             if cb["value"]:
                 line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+                line["speedup_vs_cpu_baseline_range"] = [line["value"] / cb["value_max"], line["value"] / cb["value_min"]]
                 if cb.get("hoisted", {}).get("value"):
                     line["speedup_vs_cpu_hoisted_port"] = line["value"] / cb["hoisted"]["value"]
         result = json.dumps(line)

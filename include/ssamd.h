@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSAMD_ABI_VERSION 2      /* 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
+#define SSAMD_ABI_VERSION 3      /* 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
 
 #define SSAMD_OK 0
 #define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
@@ -200,9 +200,16 @@ const char *ssamd_kernel_name(int slot);
 
 /* Experiment / test hooks.  The SSAMD_* environment variables (SSAMD_ASW_GEOM, SSAMD_ASW_PIPE,
  * SSAMD_ASW_WAVE, ... -- the same names are the option names here) are read once, when the library is loaded; this
- * call changes one of them afterwards (value NULL = unset).  No operator call reads the environment.  None of the
+ * call changes one of them afterwards (value NULL = back to what the environment had set when the library was loaded, or
+ * unset).  No operator call reads the environment.  None of the
  * options changes a disparity map: that is what the tests using them assert.  SSAMD_EINVAL for an unknown name. */
 int ssamd_set_option(const char *name, const char *value);
+
+/* Diagnostic counters of one device's context (for tests and for finding performance cliffs; never needed in
+ * production).  "evol_fallbacks": ASW calls that could not get the pre-computed TAD volume (device memory short) and
+ * ran the phase-shifted kernel with in-kernel e tiles, or a workgroup kernel instead of the small-range wave kernel;
+ * "evol_bytes": capacity of the volume buffer the context holds right now.  SSAMD_EINVAL for an unknown name. */
+int ssamd_counter(int device, const char *name, long long *value);
 
 /* Autotuning of the ASW launch geometry.  When it applies, the first ssamd_asw* call for a problem shape (width,
  * rows, winSize, number of disparities) times the best tile of every class of candidates on the call's own

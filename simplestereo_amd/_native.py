@@ -17,7 +17,7 @@ if os.environ.get("SSAMD_LIB"):
         raise ImportError("SSAMD_LIB is an experiment hook: set SSAMD_EXPERIMENT=1 as well to load %s instead of the product "
                           "library" % os.environ["SSAMD_LIB"])
     LIB_PATH = os.environ["SSAMD_LIB"]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_ASW_ALT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -111,25 +111,43 @@ def lib():
     L.ssamd_gsw_geometry.argtypes = [I, I, I, I, I, ctypes.POINTER(I)]
     L.ssamd_set_option.restype = I
     L.ssamd_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.ssamd_counter.restype = I
+    L.ssamd_counter.argtypes = [I, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]
     _lib = L
     return L
 
 
 def set_option(name, value):
-    """Experiment / test hook: set (or, with None, unset) one of the SSAMD_* tuning options of the loaded library.
-    The environment variables of the same names are only read when the library is loaded."""
+    """Experiment / test hook: set one of the SSAMD_* tuning options of the loaded library; ``None`` puts it back to what
+    the environment had set when the library was loaded (unset if it had not).  The environment variables of the same
+    names are only read at load time."""
     check(lib().ssamd_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
+def counter(name, device=-1):
+    """Diagnostic counter of a device context (``evol_fallbacks``, ``evol_bytes``: include/ssamd.h)."""
+    v = ctypes.c_longlong(0)
+    check(lib().ssamd_counter(device, name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
 class options:
-    """``with _native.options(SSAMD_ASW_GEOM="3,5,8"): ...`` -- set tuning options for a block, unset them afterwards."""
+    """``with _native.options(SSAMD_ASW_GEOM="3,5,8"): ...`` -- set tuning options for a block; afterwards every one of
+    them is back at its load-time value.  If setting one fails, the ones already set are rolled back."""
 
     def __init__(self, **kw):
         self.kw = kw
 
     def __enter__(self):
-        for k, v in self.kw.items():
-            set_option(k, v)
+        done = []
+        try:
+            for k, v in self.kw.items():
+                set_option(k, v)
+                done.append(k)
+        except Exception:
+            for k in done:
+                set_option(k, None)
+            raise
         return self
 
     def __exit__(self, *exc):

@@ -68,6 +68,7 @@ struct Tuning {
     bool no_e2 = false, xor_only = false, multi_allow_repeat = false;
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
+    int evol_fail = 0;                // test hook: 1 = the TAD volume's allocation really fails (a hipMalloc no device can serve)
 };
 std::mutex g_tune_mutex;
 std::atomic<unsigned> g_tune_version{1};
@@ -93,6 +94,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_MULTI_ALLOW_REPEAT") t.multi_allow_repeat = v != nullptr;
     else if (name == "SSAMD_ALT_QUEUE_CAP") t.alt_queue_cap = v ? std::max(1, atoi(v)) : 0;
     else if (name == "SSAMD_AUTOTUNE") t.autotune_env = v ? (atoi(v) > 0 ? 1 : (atoi(v) < 0 ? -1 : 0)) : -2;
+    else if (name == "SSAMD_ASW_EVOL_FAIL") t.evol_fail = num(0);
     else return false;
     return true;
 }
@@ -100,13 +102,17 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
-                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE"};
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL"};
 
+std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
 {
     Tuning t;
     for (const char *n : kTuningNames)
-        if (const char *v = getenv(n)) (void)tuning_assign(t, n, v);      // the only getenv calls of the library
+        if (const char *v = getenv(n)) {      // the only getenv calls of the library
+            g_tuning_env[n] = v;
+            (void)tuning_assign(t, n, v);
+        }
     return t;
 }
 Tuning g_tuning = tuning_from_env();
@@ -142,7 +148,11 @@ struct DevBuf {
         if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&ptr, want);
-        if (e != hipSuccess) { ptr = nullptr; return fail(SSAMD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            (void)hipGetLastError();      // ROCm 7 keeps the failure as the thread's last error: a caller that falls back must not see it again
+            return fail(SSAMD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
         cap = want;
         return SSAMD_OK;
     }
@@ -215,6 +225,8 @@ struct Ctx {
     TableCache proxTabs{8}, gswTabs{4};
     std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
+    int evol_small_calls = 0;           // consecutive calls that needed less than a quarter of the TAD volume's capacity
+    long long evol_fallbacks = 0;       // calls that ran without the volume (in-kernel e tiles) or off the wave kernel for lack of memory
     Profile prof;
 };
 
@@ -877,18 +889,30 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     // same GPU): never more than 24 GiB and never more than half of what is free right now (plus what the buffer already
     // holds).  The phase-shifted kernel builds its e tiles itself when there is no volume; the wave kernel cannot, so
     // a range it would serve falls back to the workgroup geometry stored next to it.
-    size_t evol_limit = (size_t)24 << 30;
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) evol_limit = std::min(evol_limit, c.evol.cap + free_b / 2);
-        if (tune().evol_max_mb) evol_limit = std::min(evol_limit, (size_t)tune().evol_max_mb << 20);
-    }
+    // Free memory is only asked for (a driver query, tens of microseconds next to a 0.1 ms Tsukuba call) when a volume
+    // would have to GROW: what fits the buffer the context already holds fits.
+    const size_t evol_cap_max = tune().evol_max_mb ? std::min((size_t)24 << 30, (size_t)tune().evol_max_mb << 20) : (size_t)24 << 30;
+    size_t evol_limit_cached = 0;
+    bool evol_limit_known = false;
+    auto evol_fits = [&](size_t bytes) {
+        if (bytes > evol_cap_max) return false;
+        if (bytes <= c.evol.cap) return true;
+        if (!evol_limit_known) {
+            size_t free_b = 0, total_b = 0;
+            evol_limit_cached = evol_cap_max;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) evol_limit_cached = std::min(evol_cap_max, c.evol.cap + free_b / 2);
+            else (void)hipGetLastError();
+            evol_limit_known = true;
+        }
+        return bytes <= evol_limit_cached;
+    };
     auto wave_volume_fits = [&](const AswGeom &g) {
         AswWaveGeom wg;
         if (!g.wave_rx || !asw_wave_layout(wg, win, nD, g.wave_rx)) return !g.wave_rx;
         const int xt = (W + wg.Txw - 1) / wg.Txw, erows = std::min(H, row0 + rows + win / 2) - std::max(0, row0 - win / 2);
-        return (size_t)erows * (size_t)round_up(xt * wg.Txw + 2 * (win / 2), 4) * (size_t)wg.Se + 4096 <= evol_limit;
+        return evol_fits((size_t)erows * (size_t)round_up(xt * wg.Txw + 2 * (win / 2), 4) * (size_t)wg.Se + 4096);
     };
+    if (nD >= 1 && a.g.wave_rx && !wave_volume_fits(a.g)) ++c.evol_fallbacks;
     if (nD >= 1 && !wave_volume_fits(a.g)) a.g.wave_rx = 0;
     trial.erase(std::remove_if(trial.begin(), trial.end(), [&](const AswGeom &g) { return !wave_volume_fits(g); }), trial.end());
     if (trial.size() < 2) trial.clear();
@@ -942,17 +966,35 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             const int xt = (W + Tx - 1) / Tx;
             const int evolW = round_up(xt * Tx + 2 * p, 4);           // rows stay 16-byte aligned for any Se
             const size_t bytes = (size_t)chunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)Se;
-            // (evol_limit: see above; a buffer four times larger than a later call needs is given back)
-            const size_t limit = evol_limit;
+            // A buffer four times larger than the calls need is given back -- but only after eight such calls in a row
+            // and never between the trial launches of the autotuner: a workload alternating a large and a small shape
+            // (or the tuner's round-robin over wave and workgroup candidates) must not pay a device synchronisation,
+            // a hipFree and a hipMalloc per switch.
             if (c.evol.cap > ((size_t)256 << 20) && (bytes + 4096) * 4 < c.evol.cap) {
-                (void)hipStreamSynchronize(s);                        // (earlier launches of this call may still read it)
-                c.evol.release();
+                if (trial.empty() && ++c.evol_small_calls >= 8) {
+                    (void)hipStreamSynchronize(s);                    // (earlier launches of this call may still read it)
+                    c.evol.release();
+                    c.evol_small_calls = 0;
+                }
+            } else {
+                c.evol_small_calls = 0;
             }
-            int erc = bytes <= limit ? c.evol.reserve(bytes + 4096) : SSAMD_ENOMEM;     // + one DMA piece of slack behind the last tile
+            int erc = SSAMD_ENOMEM;
+            if (tune().evol_fail) {                                   // test hook: a hipMalloc that really fails
+                void *none = nullptr;
+                size_t free_b = 0, total_b = (size_t)512 << 30;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                if (hipMalloc(&none, 2 * total_b) == hipSuccess) (void)hipFree(none);     // twice the device's memory
+                // (deliberately NOT drained here: the fallback below has to cope with the sticky error itself)
+            } else if (evol_fits(bytes + 4096)) {
+                erc = c.evol.reserve(bytes + 4096);                   // + one DMA piece of slack behind the last tile
+            }
             if (erc) {
+                (void)hipGetLastError();      // a failed hipMalloc stays the thread's last HIP error on ROCm 7: drop it before the launches' checks
                 // the phase-shifted kernel builds its e tiles itself when there is no volume (A.evol == nullptr);
                 // only the wave kernel cannot run without one
                 if (g.wave_rx) return fail(erc == SSAMD_ENOMEM ? SSAMD_ENOMEM : erc, "TAD volume of %zu bytes does not fit the device memory left", bytes);
+                ++c.evol_fallbacks;
                 g_err.clear();
                 return SSAMD_OK;
             }
@@ -1041,7 +1083,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             // first launches after an idle period, so timing the candidates one after the other would favour the
             // late ones
             std::vector<float> cand_ms(trial.size(), 3.0e38f);
-            for (const AswGeom &g : trial) { (void)prepare_evol(g); (void)launch(g); }    // code load, clocks, scratch
+            for (const AswGeom &g : trial)                                                // code load, clocks, scratch
+                if (prepare_evol(g) == SSAMD_OK) (void)launch(g);                        // (a wave candidate whose volume cannot be had is never launched)
             for (int round = 0; round < 4; ++round)
                 for (size_t ci = 0; ci < trial.size(); ++ci) {
                     float ms = 3.0e38f;
@@ -1126,10 +1169,10 @@ int asw_alternate_rows(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int 
 }
 
 // ------------------------------------------------------------ GSW
-bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int Hy = 1)
+bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int Hy = 1, int pipe = 0)
 {
     const int p = win / 2;
-    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = Ty == 2 ? 4 : 8; g.Hy = Hy;
+    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = 8 / Ty; g.Hy = Hy; g.pipe = pipe;       // thread tile: Ty rows x 4 columns x 8 / Ty disparities = 32 accumulators
     g.Tx = GSW_RX * XG; g.Dc = g.Rd * DG;
     g.threads = round_up(XG * DG, 64);
     g.nL = g.Tx + 2 * p;
@@ -1142,14 +1185,18 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int H
     g.emask = std::min(P, 32) - 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    g.off_w = take((size_t)Ty * Hy * win * g.Tx * 4);
+    const int nbuf = pipe ? 2 : 1;                     // phase-shifted kernel: weights and e tile of image row r + 1 next to those of row r
+    g.off_w = take((size_t)nbuf * Ty * Hy * win * g.Tx * 4);
     const int nL4 = round_up(g.nL, 4);                 // the e tasks cover 4 columns
-    g.off_e = take((size_t)nL4 * g.Se * 4);
+    g.off_e = take((size_t)nbuf * nL4 * g.Se * 4);
     g.off_ref = take((size_t)nL4 * 16 * 2);            // pixel staging is double-buffered (prefetch of the next image row)
     g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16 * 2);
     g.off_best = take((size_t)Ty * Hy * g.Tx * 8);
     g.off_cen = take((size_t)Ty * Hy * g.Tx * 4);
     g.lds_bytes = (int)off;
+    if (pipe)       // two-row thread tiles; a thread stages at most two pixels per image row
+        return off <= limit && Ty == 2 && g.threads * Hy <= GSW_PIPE_MAX_THREADS && g.threads <= GSW_MAX_THREADS &&
+               nL4 + g.nT + nL4 - g.nL <= 2 * g.threads * Hy;
     return off <= limit && g.threads * Hy <= GSW_MAX_THREADS;
 }
 
@@ -1178,9 +1225,9 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
 {
     if (!tune().gsw_geom.empty()) {                             // experiment hook: "XG,DG,Ty"
         const char *const env = tune().gsw_geom.c_str();
-        int XG = 0, DG = 0, Ty = 1, Hy = 1;                       // "XG,DG[,Ty[,Hy]]"
-        if (sscanf(env, "%d,%d,%d,%d", &XG, &DG, &Ty, &Hy) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) && Hy >= 1 && Hy <= 8 &&
-            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024, Hy)) {
+        int XG = 0, DG = 0, Ty = 1, Hy = 1, pipe = 0;              // "XG,DG[,Ty[,Hy[,pipe]]]"
+        if (sscanf(env, "%d,%d,%d,%d,%d", &XG, &DG, &Ty, &Hy, &pipe) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2 || Ty == 4) && Hy >= 1 && Hy <= 8 &&
+            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024, Hy, pipe ? 1 : 0)) {
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
             return SSAMD_OK;
         }
@@ -1297,7 +1344,7 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.iterations = iterations; a.fMax = fMax;
         const int TyS = a.g.Ty * a.g.Hy;
         const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + TyS - 1) / TyS, a.g.nchunks), block(a.g.threads * a.g.Hy);
-        auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
+        auto kernel = a.g.pipe ? gsw_aggregate_pipe_kernel<4> : a.g.Ty == 4 ? gsw_aggregate_kernel<4, 2> : a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
         if ((rc = grant_dyn_lds(c, (const void *)kernel, a.g.lds_bytes))) return rc;
         for (int pass = 0; pass < 2; ++pass) {
             a.right = pass;
@@ -1478,9 +1525,31 @@ int ssamd_set_option(const char *name, const char *value)
 {
     if (!name) return fail(SSAMD_EINVAL, "option name is NULL");
     std::lock_guard<std::mutex> lk(g_tune_mutex);
-    if (!tuning_assign(g_tuning, name, value)) return fail(SSAMD_EINVAL, "unknown option %s", name);
-    if (std::string(name) == "SSAMD_AUTOTUNE" && value) g_autotune.store(g_tuning.autotune_env);
+    if (value) {
+        if (!tuning_assign(g_tuning, name, value)) return fail(SSAMD_EINVAL, "unknown option %s", name);
+    } else {
+        // NULL = back to the value the library loaded from the environment (not "unset": a process started with
+        // SSAMD_ASW_WAVE=0 keeps that setting after a `with options(...)` block of a test)
+        const auto it = g_tuning_env.find(name);
+        if (!tuning_assign(g_tuning, name, it == g_tuning_env.end() ? nullptr : it->second.c_str()))
+            return fail(SSAMD_EINVAL, "unknown option %s", name);
+    }
+    if (std::string(name) == "SSAMD_AUTOTUNE")
+        g_autotune.store(g_tuning.autotune_env != -2 ? g_tuning.autotune_env : -1);
     g_tune_version.fetch_add(1, std::memory_order_release);
+    return SSAMD_OK;
+}
+
+int ssamd_counter(int device, const char *name, long long *value)
+{
+    if (!name || !value) return fail(SSAMD_EINVAL, "name / value is NULL");
+    CtxLock c;
+    int rc = get_ctx(device, c);
+    if (rc) return rc;
+    const std::string n(name);
+    if (n == "evol_fallbacks") *value = c->evol_fallbacks;
+    else if (n == "evol_bytes") *value = (long long)c->evol.cap;
+    else return fail(SSAMD_EINVAL, "unknown counter %s", name);
     return SSAMD_OK;
 }
 

@@ -3,6 +3,8 @@ _passive.cpp), the C-ABI library loads and exports every symbol of include/ssamd
 and the product refuses to run without a GPU (no CPU fallback)."""
 import inspect
 import os
+import subprocess
+import sys
 import re
 
 import numpy as np
@@ -146,6 +148,37 @@ def test_tuning_options_are_a_table_not_the_environment(ss):
     assert _native.asw_kernel_form(1920, 10, 35, 16, 0) == f0
     with pytest.raises(_native.NativeError):
         _native.set_option("SSAMD_NO_SUCH_OPTION", "1")
+
+
+def test_options_go_back_to_the_environment_baseline():
+    """`with options(...)` / set_option(name, None) restore what the process was STARTED with, not "unset": a process
+    launched with SSAMD_ASW_WAVE=0 keeps that after a block that overrides it; SSAMD_AUTOTUNE=NULL restores the mode too;
+    a block whose second option is refused rolls the first one back"""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from simplestereo_amd import _native
+q = lambda: _native.asw_kernel_form(1920, 10, 35, 16, 0)["wave_kernel"]
+assert q() == 0                                   # from the environment
+with _native.options(SSAMD_ASW_WAVE="1"):
+    assert q() in (4, 8)
+assert q() == 0, "the load-time value must come back"
+lib = _native.lib()
+assert lib.ssamd_autotune(1) == 0                 # SSAMD_AUTOTUNE=0 from the environment; now forced on
+_native.set_option("SSAMD_AUTOTUNE", "1")
+_native.set_option("SSAMD_AUTOTUNE", None)
+assert lib.ssamd_autotune(-1) == 0, "NULL restores the environment's autotune mode"
+try:
+    with _native.options(SSAMD_ASW_WAVE="1", SSAMD_NO_SUCH_OPTION="1"):
+        raise SystemExit("the unknown option must be refused")
+except _native.NativeError:
+    pass
+assert q() == 0, "the option set before the refused one must be rolled back"
+print("ok")
+""" % ROOT
+    env = dict(os.environ, SSAMD_ASW_WAVE="0", SSAMD_AUTOTUNE="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-800:]
 
 
 def test_geometry_query_is_sane(ss):

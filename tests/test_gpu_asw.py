@@ -400,6 +400,53 @@ def test_asw_without_room_for_the_tad_volume(shape, win, maxd, consistent, ss):
     assert torch.equal(m.compute(tL, tR), want)
 
 
+def test_asw_when_the_tad_volume_allocation_really_fails(ss):
+    """SSAMD_ASW_EVOL_FAIL makes the volume's allocation a hipMalloc no device can serve: the failure is HIP's sticky last
+    error on ROCm 7, and the advertised fallback (phase-shifted kernel with in-kernel e tiles) must still run -- same map,
+    the fallback counted, and the next ordinary call gets its volume again"""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(40, 300, 70, 9)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(winSize=35, maxDisparity=70)
+    assert _native.asw_kernel_form(300, 40, 35, 70, 0)["phase_shifted"] == 1
+    want = m.compute(tL, tR)
+    n0 = _native.counter("evol_fallbacks")
+    with _native.options(SSAMD_ASW_EVOL_FAIL="1"):
+        got = m.compute(tL, tR)
+        assert torch.equal(got, want)
+        assert _native.counter("evol_fallbacks") == n0 + 1
+        # the small-range wave kernel cannot run without its volume: a clean error, no stale HIP error afterwards
+        with pytest.raises(_native.NativeError):
+            ss.passive.StereoASW(winSize=35, maxDisparity=16).compute(tL, tR)
+    assert torch.equal(m.compute(tL, tR), want)
+    assert _native.counter("evol_fallbacks") == n0 + 1 and _native.counter("evol_bytes") > 0
+    assert ss.passive.StereoASW(winSize=35, maxDisparity=16).compute(tL, tR).shape == (40, 300)
+
+
+def test_tad_volume_is_not_released_on_every_switch_of_shape(ss):
+    """a workload alternating a large and a small shape keeps the larger volume (given back only after eight small calls
+    in a row): no hipFree / hipMalloc per switch"""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(800, 1920, 192, 2)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    big = ss.passive.StereoASW(winSize=35, maxDisparity=192)
+    small = ss.passive.StereoASW(winSize=35, maxDisparity=16)
+    sL, sR = tL[:48].contiguous(), tR[:48].contiguous()
+    big.compute(tL, tR)
+    cap = _native.counter("evol_bytes")
+    if cap <= (256 << 20):
+        pytest.skip("the volume of this frame is below the release threshold")
+    for _ in range(3):
+        small.compute(sL, sR)
+        assert _native.counter("evol_bytes") == cap
+        big.compute(tL, tR)
+    for _ in range(9):
+        small.compute(sL, sR)
+    assert _native.counter("evol_bytes") < cap
+
+
 @pytest.mark.parametrize("win,maxd,mind,consistent", [(35, 16, 0, False), (35, 16, 0, True), (15, 17, 0, True), (7, 21, 5, False), (63, 18, 2, True),
                                                        (11, 22, 5, True)])
 def test_asw_wave_kernel_six_disparities_per_lane(win, maxd, mind, consistent, ss, golden_inputs):

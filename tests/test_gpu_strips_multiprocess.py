@@ -54,6 +54,9 @@ def _worker(rank, world, port, case, q):
     (3, ("asw", 50, 160, dict(winSize=35, maxDisparity=24, minDisparity=2))),      # strips thinner than the halo
     (2, ("gsw", 45, 150, dict(winSize=11, maxDisparity=30))),
     (3, ("asw", 47, 160, dict(winSize=11, maxDisparity=24, alternate=True))),      # strips of 16 / 16 / 15 rows: odd and even starts
+    # BASELINE config 5's partition: eight ranks, 4096 columns, D 0..256, win 35 (the 88 x 260 tiles of the 4K launch); 136
+    # rows = eight strips of 17 rows = exactly the halo, so every interior rank receives both halos whole from its neighbours
+    (8, ("asw", 136, 4096, dict(winSize=35, maxDisparity=256))),
 ])
 def test_strips_across_processes_reproduce_the_whole_frame(world, case):
     import torch.multiprocessing as mp
@@ -63,7 +66,7 @@ def test_strips_across_processes_reproduce_the_whole_frame(world, case):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=480) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
