@@ -208,7 +208,8 @@ int ssamd_set_option(const char *name, const char *value);
 /* Diagnostic counters of one device's context (for tests and for finding performance cliffs; never needed in
  * production).  "evol_fallbacks": ASW calls that could not get the pre-computed TAD volume (device memory short) and
  * ran the phase-shifted kernel with in-kernel e tiles, or a workgroup kernel instead of the small-range wave kernel;
- * "evol_bytes": capacity of the volume buffer the context holds right now.  SSAMD_EINVAL for an unknown name. */
+ * "evol_bytes": capacity of the volume buffer the context holds right now; "tail_splits": phase-shifted launches whose last
+ * partial round of workgroups ran as half-width tiles.  SSAMD_EINVAL for an unknown name. */
 int ssamd_counter(int device, const char *name, long long *value);
 
 /* Autotuning of the ASW launch geometry.  When it applies, the first ssamd_asw* call for a problem shape (width,

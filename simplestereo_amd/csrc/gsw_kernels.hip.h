@@ -40,8 +40,6 @@ struct GswGeom {
     int Hy;                         // round 3: thread groups of `threads` lanes each; group h owns output rows Ty*h .. Ty*h + Ty - 1 of the
                                     // workgroup's strip of Ty*Hy rows, all groups share the e tile of an image row
     int nL, nT, Se, emask, Ses;     // Se = 1 << Ses: floats per e row (32-byte slots, XOR-swizzled)
-    int pipe;                       // round 4: 1 = gsw_aggregate_pipe_kernel (two e tiles and two weight buffers: image row r + 1 is
-                                    // built while row r is tapped, one barrier per image row, waves in two shifted phases)
     int off_w, off_e, off_ref, off_tgt, off_best, off_cen;
     int lds_bytes;
 };
@@ -115,12 +113,7 @@ __device__ __forceinline__ void gsw_taps(float (&cost)[GSW_RX][RD], const float4
 template <int RD>
 __device__ __forceinline__ void gsw_load_row(float (&row)[RD], const float *e)
 {
-    static_assert(RD == 2 || RD == 4 || RD == 8, "thread tiles of 2, 4 or 8 disparities");
-    if constexpr (RD == 2) {
-        const float2 a = *reinterpret_cast<const float2 *>(e);
-        row[0] = a.x; row[1] = a.y;
-        return;
-    }
+    static_assert(RD == 4 || RD == 8, "thread tiles of 4 or 8 disparities");
     const float4 a = *reinterpret_cast<const float4 *>(e);
     row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w;
     if constexpr (RD == 8) {
@@ -139,8 +132,7 @@ __device__ __forceinline__ void gsw_row_taps(float (&cost)[TY][GSW_RX][RD], cons
 {
     const float *wp = wS + GSW_RX * xg;
     const int wstride = win * Tx, pitch = 1 << Ses;
-    constexpr int PER = 8 / RD;                                                    // disparity groups per 8-float slot
-    const int slot = dg / PER, half = RD * (dg % PER);                             // dg-th group of RD disparities
+    const int slot = RD == 8 ? dg : dg >> 1, half = RD == 8 ? 0 : 4 * (dg & 1);    // dg-th group of RD disparities
     auto key = [&](int k) { return ((slot ^ ((xg + k) & emask)) << 3) + half; };
     const float *er = eT + ((GSW_RX * xg) << Ses);       // row ul0 + j0
     int kA = key(0), kB = key(1);
@@ -164,95 +156,6 @@ __device__ __forceinline__ void gsw_row_taps(float (&cost)[TY][GSW_RX][RD], cons
         kB = key(j0 / 4 + 2);
     }
 #undef SSAMD_GSTEP
-}
-
-// ---- support weights of image row r for the tile's reference pixels, per output row of the strip:
-//      image row r is window row i = r - y + pad of output row y.  A thread keeps one reference
-//      column c (its centre pixel is fetched once) and walks the tap columns j.
-//      (A flat deal of (row, tap column) pairs over the threads -- for tall strips of narrow tiles, where a thread per
-//      tap column leaves threads idle -- was built and measured in round 3: +2 % on two-row strips from its per-task
-//      index arithmetic; dropped.)
-__device__ __forceinline__ void gsw_build_weights(const GswArgs &A, int tid, int nthr, int r, int y0, int ny, int x0, int TYS,
-                                                  const GswPix *refS, const uint32_t *cenS, float *wS)
-{
-    const GswGeom &g = A.g;
-    const int W = A.W, win = A.win, p = A.pad, Tx = g.Tx;
-    const bool right = A.right != 0;
-    const int lanesX = min(Tx, nthr), qw = nthr / lanesX;
-    const int c0 = tid % lanesX, jq = tid / lanesX;
-    if (jq >= qw) return;
-    for (int c = c0; c < Tx; c += lanesX) {
-        const int x = x0 + c;
-        for (int t = 0; t < TYS; ++t) {          // the weights of every output row of the strip
-            if (!(t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win)) continue;
-            const int y = y0 + t, i = r - y + p;
-            float *const wT = wS + t * win * Tx + c;
-            bool reached = A.iterations > 0 && x < W;
-            if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
-            const GswPix cpx = gsw_pix(cenS[t * Tx + c], 1.f, 0.f);
-            // two tap columns per batch, branch-free: their table gathers are in flight together
-            for (int jb = jq; jb < win; jb += 2 * qw) {
-                float w[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int j = min(jb + u * qw, win - 1);
-                    const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
-                    const bool centre = i == p && j == p;
-                    const bool gather = reached && !centre && px.inside != 0.f;
-                    const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
-                    w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (jb + u * qw < win) wT[(jb + u * qw) * Tx] = w[u];
-            }
-        }
-    }
-}
-
-// ---- e[ul][d] = min(fMax, ||ref(r,u) - tgt(r,u -/+ d)||), 0 when the target column is outside.
-//      A task is four adjacent columns ul = 4m .. 4m+3 at one disparity dd: they share the swizzle
-//      key, so one address computation serves four independent sub/dot/sqrt chains.  Each thread
-//      keeps its dd and walks m with a constant stride; dd is fastest across the lanes of a wave:
-//      the e writes of a wave fall into consecutive floats, the reference pixels are broadcast
-//      reads and the target pixels consecutive 16-byte reads.  (nL is padded to a multiple of 4;
-//      the padding columns hold outside-the-image pixels and are never read by the taps.)
-__device__ __forceinline__ void gsw_build_e(const GswGeom &g, int tid, int nthr, bool right, const GswPix *refS, const GswPix *tgtS,
-                                            float *eT)
-{
-    const int Dc = g.Dc, nL = g.nL, Ses = g.Ses, emask = g.emask;
-    const int lanesD = min(Dc, nthr), q = nthr / lanesD;
-    const int dd0 = tid % lanesD, mq = tid / lanesD;
-    if (mq >= q) return;
-    for (int dd = dd0; dd < Dc; dd += lanesD) {
-        const int tofs = right ? dd : (Dc - 1) - dd;
-        const int eofs = dd & 7, slot = dd >> 3;
-        // running pointers: per task one add each for the pixels and the e rows, and the swizzled slot
-        // (gsw_e_offset: (ul << Ses) + ((slot ^ ((ul >> 2) & emask)) << 3) with ul = 4 m)
-        const int pitch = 1 << Ses, rstep = 4 * q;
-        const GswPix *rp = refS + 4 * mq, *tp = tgtS + 4 * mq + tofs;
-        float *erow = eT + ((4 * mq) << Ses) + eofs;
-        for (int m = mq; 4 * m < nL; m += q, rp += rstep, tp += rstep, erow += rstep << Ses) {
-            int swz = (slot ^ (m & emask)) << 3;
-            asm volatile("" : "+v"(swz));          // one base, the three other rows at + k * pitch (not four running pointers)
-            float *const ep = erow + swz;
-            GswPix rv[4], tv[4];
-            float ev[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { rv[u] = rp[u]; tv[u] = tp[u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(tv[u].inside));      // keeps the target reads ds_read_b128 (the 12-byte form is twice as slow)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ev[u] = (float)gsw_dist2(rv[u], tv[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float d = gsw_sqrt_int(ev[u]);
-                // v_min_f32 as written: fminf() would first canonicalise the cap it has just read from LDS (one more instruction per element)
-                asm("v_min_f32 %0, %1, %2" : "=v"(ev[u]) : "v"(tv[u].cap), "v"(d));
-            }
-            ep[0] = ev[0]; ep[pitch] = ev[1]; ep[2 * pitch] = ev[2]; ep[3 * pitch] = ev[3];
-        }
-    }
 }
 
 template <int TY, int RD>
@@ -339,11 +242,88 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
 #ifdef SSAMD_GABLATE_W
         if (r == r_lo)
 #endif
-        gsw_build_weights(A, tid, nthr, r, y0, ny, x0, TYS, refS, cenS, wS);
+        {
+            // a thread keeps one reference column c and walks (output row of the strip, tap column) with its centre pixel
+            // fetched once per row.  (A flat deal of (row, tap column) pairs over the threads -- for tall strips of
+            // narrow tiles, where a thread per tap column leaves threads idle -- was built and measured in round 3:
+            // +2 % on two-row strips from its per-task index arithmetic; dropped together with tall strips as the default.)
+            const int lanesX = min(Tx, nthr), qw = nthr / lanesX;
+            const int c0 = tid % lanesX, jq = tid / lanesX;
+            if (jq < qw) {
+                for (int c = c0; c < Tx; c += lanesX) {
+                    const int x = x0 + c;
+                    for (int t = 0; t < TYS; ++t) {          // the weights of every output row of the strip
+                        if (!(t < ny && (unsigned)(r - (y0 + t) + p) < (unsigned)win)) continue;
+                        const int y = y0 + t, i = r - y + p;
+                        float *const wT = wS + t * win * Tx + c;
+                        bool reached = A.iterations > 0 && x < W;
+                        if (!right && x + p >= W) reached = reached && (y == 0) && (i == p);   // left-pass break quirk
+                        const GswPix cpx = gsw_pix(cenS[t * Tx + c], 1.f, 0.f);
+                        // two tap columns per batch, branch-free: their table gathers are in flight together
+                        for (int jb = jq; jb < win; jb += 2 * qw) {
+                            float w[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int j = min(jb + u * qw, win - 1);
+                                const GswPix px = refS[c + j];      // .inside: tap column x - pad + j is in the image
+                                const bool centre = i == p && j == p;
+                                const bool gather = reached && !centre && px.inside != 0.f;
+                                const float tw = A.tab[gather ? gsw_dist2(px, cpx) : 0u];
+                                w[u] = gather ? tw : (centre && x < W ? 1.0f : 0.f);      // centre: exp(-0/gamma)
+                            }
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                if (jb + u * qw < win) wT[(jb + u * qw) * Tx] = w[u];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- e[ul][d] = min(fMax, ||ref(r,u) - tgt(r,u -/+ d)||), 0 when the target column is outside.
+        //      A task is four adjacent columns ul = 4m .. 4m+3 at one disparity dd: they share the swizzle
+        //      key, so one address computation serves four independent sub/dot/sqrt chains.  Each thread
+        //      keeps its dd and walks m with a constant stride; dd is fastest across the lanes of a wave:
+        //      the e writes of a wave fall into consecutive floats, the reference pixels are broadcast
+        //      reads and the target pixels consecutive 16-byte reads.  (nL is padded to a multiple of 4;
+        //      the padding columns hold outside-the-image pixels and are never read by the taps.)
 #ifdef SSAMD_GABLATE_E
         if (r == r_lo)
 #endif
-        gsw_build_e(g, tid, nthr, right, refS, tgtS, eT);
+        {
+            const int lanesD = min(Dc, nthr), q = nthr / lanesD;
+            const int dd0 = tid % lanesD, mq = tid / lanesD;
+            if (mq < q) {
+                for (int dd = dd0; dd < Dc; dd += lanesD) {
+                    const int tofs = right ? dd : (Dc - 1) - dd;
+                    const int eofs = dd & 7, slot = dd >> 3;
+                    // running pointers: per task one add each for the pixels and the e rows, and the swizzled slot
+                    // (gsw_e_offset: (ul << Ses) + ((slot ^ ((ul >> 2) & emask)) << 3) with ul = 4 m)
+                    const int pitch = 1 << Ses, rstep = 4 * q;
+                    const GswPix *rp = refS + 4 * mq, *tp = tgtS + 4 * mq + tofs;
+                    float *erow = eT + ((4 * mq) << Ses) + eofs;
+                    for (int m = mq; 4 * m < nL; m += q, rp += rstep, tp += rstep, erow += rstep << Ses) {
+                        int swz = (slot ^ (m & emask)) << 3;
+                        asm volatile("" : "+v"(swz));          // one base, the three other rows at + k * pitch (not four running pointers)
+                        float *const ep = erow + swz;
+                        GswPix rv[4], tv[4];
+                        float ev[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { rv[u] = rp[u]; tv[u] = tp[u]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(tv[u].inside));      // keeps the target reads ds_read_b128 (the 12-byte form is twice as slow)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ev[u] = (float)gsw_dist2(rv[u], tv[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float d = gsw_sqrt_int(ev[u]);
+                            // v_min_f32 as written: fminf() would first canonicalise the cap it has just read from LDS (one more instruction per element)
+                            asm("v_min_f32 %0, %1, %2" : "=v"(ev[u]) : "v"(tv[u].cap), "v"(d));
+                        }
+                        ep[0] = ev[0]; ep[pitch] = ev[1]; ep[2 * pitch] = ev[2]; ep[3 * pitch] = ev[3];
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (r < r_hi) stage_row(r + 1, (r + 1) & 1);       // prefetch: its global latency sits under the taps below
 
@@ -354,33 +334,11 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
             const float *const wG = wS + (TY * grp) * win * Tx;       // this group's weight rows
             if constexpr (TY == 1) {
                 if (use[0]) gsw_row_taps<1, RD, 0, 1>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
-            } else if constexpr (TY == 2) {
+            } else {
+                static_assert(TY == 2, "thread tiles of 1 or 2 output rows");
                 if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
                 else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
                 else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
-            } else {
-                // four output rows per thread (round 4): the rows whose windows contain this image row are a contiguous run
-                // [t0, t1) -- one straight-line tap loop per run that occurs (a prefix, a suffix or, for windows shorter than
-                // the strip, a run in the middle)
-                static_assert(TY == 4, "thread tiles of 1, 2 or 4 output rows");
-                int t0 = 0, t1 = 0;
-#pragma unroll
-                for (int t = TY - 1; t >= 0; --t) if (use[t]) t0 = t;
-#pragma unroll
-                for (int t = 0; t < TY; ++t) if (use[t]) t1 = t + 1;
-                switch (t0 * 8 + t1) {
-                case 0 * 8 + 4: gsw_row_taps<4, RD, 0, 4>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 0 * 8 + 3: gsw_row_taps<4, RD, 0, 3>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 0 * 8 + 2: gsw_row_taps<4, RD, 0, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 0 * 8 + 1: gsw_row_taps<4, RD, 0, 1>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 1 * 8 + 4: gsw_row_taps<4, RD, 1, 4>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 2 * 8 + 4: gsw_row_taps<4, RD, 2, 4>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 3 * 8 + 4: gsw_row_taps<4, RD, 3, 4>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 1 * 8 + 2: gsw_row_taps<4, RD, 1, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 1 * 8 + 3: gsw_row_taps<4, RD, 1, 3>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                case 2 * 8 + 3: gsw_row_taps<4, RD, 2, 3>(cost, wG, eT, win, Tx, xg, dg, Ses, emask); break;
-                default: break;
-                }
             }
         }
     }
@@ -402,165 +360,6 @@ __global__ __launch_bounds__(GSW_MAX_THREADS, 4) void gsw_aggregate_kernel(const
                     if (valid) b = min(b, make_key(cost[t][xi][di], right ? (uint32_t)(x + d) : (uint32_t)d));
                 }
                 if (b != KEY_NONE) atomicMin(&best[(TY * grp + t) * Tx + GSW_RX * xg + xi], b);
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < ny * Tx; k += nthr) {
-        const int t = k / Tx, c = k - t * Tx;
-        const int x = x0 + c;
-        if (x < W && best[k] != KEY_NONE) atomicMin(&A.key[(size_t)(y0 + t - A.row0) * W + x], best[k]);
-    }
-}
-
-// K3p / K4p (round 4): the phase-shifted form of the GSW kernel -- the structure of asw_aggregate_pipe_kernel.
-//
-// gsw_aggregate_kernel rebuilds the e tile of an image row for every strip of TY = 2 output rows whose windows contain
-// it ((win + 1) / 2 = 6 times per output row at win 11) and walks build | barrier | taps | barrier per image row; two
-// 8-wave workgroups per CU interleave by chance.  Taller strips need more threads per tile (the thread tile is pinned at
-// 2 rows x 4 columns x 4 disparities by the 128-VGPR budget): a 16-wave workgroup in lockstep lost more at its barriers
-// than the saved e elements gave (round 3: 9.94 against 8.71 ms).
-//
-// Here a workgroup is Hy thread groups of g.threads lanes (ONE workgroup of up to 16 waves per CU); group h owns output
-// rows 2 h, 2 h + 1 of a strip of 2 Hy rows, and everything built per image row -- staged pixels, support weights, e tile
-// -- is double-buffered, so that the build for image row r + 1 only touches buffers the taps of row r do not read:
-//     iteration r:   taps(r)  |  build(r + 1): weights + e tile  |  stage(r + 2): global -> LDS      then ONE barrier
-// and the waves follow two orders, two of the four waves of every SIMD each (wave >> 2 odd / even):
-//     build(r + 1), taps(r)      or      taps(r), build(r + 1)
-// so that the gather- and sqrt-latency of a build runs under the multiply-add stream of the SIMD-mates.
-// A four-row strip rebuilds an e row (win + 3) / 4 = 3.5 times per output row instead of 6.
-// Same taps in the same order per (x, d) as gsw_aggregate_kernel: bit-identical costs, hence maps.
-static constexpr int GSW_PIPE_MAX_THREADS = 1024;
-
-template <int RD>
-__global__ __launch_bounds__(GSW_PIPE_MAX_THREADS) void gsw_aggregate_pipe_kernel(const GswArgs A)
-{
-    constexpr int TY = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const GswGeom &g = A.g;
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int W = A.W, H = A.H, win = A.win, p = A.pad;
-    const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nT = g.nT, Ses = g.Ses, emask = g.emask;
-    const int nL4 = (nL + 3) & ~3, nT4 = nT + (nL4 - nL);
-    const int TYS = TY * g.Hy;
-    const int wfl = TYS * win * Tx, efl = nL4 << Ses;            // floats of one weight buffer / one e tile
-    float *const wS0 = reinterpret_cast<float *>(smem + g.off_w);          // [2][TYS][win][Tx]
-    float *const eT0 = reinterpret_cast<float *>(smem + g.off_e);          // [2][nL4][Se]
-    GswPix *const refS0 = reinterpret_cast<GswPix *>(smem + g.off_ref);   // [2][nL4]
-    GswPix *const tgtS0 = reinterpret_cast<GswPix *>(smem + g.off_tgt);   // [2][nT4]
-    u64 *const best = reinterpret_cast<u64 *>(smem + g.off_best);         // [TYS][Tx]
-    uint32_t *const cenS = reinterpret_cast<uint32_t *>(smem + g.off_cen); // [TYS][Tx]
-
-    const int x0 = blockIdx.x * Tx;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = __builtin_amdgcn_readfirstlane(tid / g.threads), gtid = tid - grp * g.threads;
-    const int phase = (wave >> 2) & 1;                            // two of the four waves of a SIMD each (waves w, w + 4, ... share one)
-    const int y0 = A.row0 + blockIdx.y * TYS;
-    const int ny = min(TYS, A.row0 + A.rows - y0);
-    const int yg = y0 + TY * grp;
-    const int dlo = A.minD + blockIdx.z * Dc;
-    const int dhi = dlo + Dc - 1;
-    const bool right = A.right != 0;
-    if (!right && min(x0 + Tx - 1, W - 1) - dlo < 0) return;
-    if (right && x0 + dlo > W - 1) return;
-    const int seg_lo = x0 - p;
-    const int tgt_lo = right ? seg_lo + dlo : seg_lo - dhi;
-    const bool active = gtid < g.XG * g.DG && TY * grp < ny;
-    const int xg = gtid % g.XG, dg = gtid / g.XG;
-
-    float cost[TY][GSW_RX][RD];
-#pragma unroll
-    for (int t = 0; t < TY; ++t)
-#pragma unroll
-        for (int a = 0; a < GSW_RX; ++a)
-#pragma unroll
-            for (int b = 0; b < RD; ++b) cost[t][a][b] = 0.f;
-    for (int k = tid; k < TYS * Tx; k += nthr) {
-        best[k] = KEY_NONE;
-        const int t = k / Tx, c = k - t * Tx;
-        cenS[k] = (t < ny && x0 + c < W) ? A.ref[(size_t)(y0 + t) * W + x0 + c] : 0u;
-    }
-    const int r_lo = max(0, y0 - p), r_hi = min(H - 1, y0 + ny - 1 + p);
-
-    // pixel staging in two halves: the global loads are issued at the start of an iteration and written to LDS at its end,
-    // so their latency sits under the iteration's taps (thread k stages column k of the reference segment, then of the target one)
-    const int nstage = nL4 + nT4;
-    auto stage_issue = [&](int rr, uint32_t (&v)[2], bool (&in)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = tid + q * nthr;
-            const bool isRef = k < nL4;
-            const int col = (isRef ? seg_lo : tgt_lo) + (isRef ? k : k - nL4);
-            in[q] = k < nstage && (unsigned)col < (unsigned)W;
-            v[q] = in[q] ? (isRef ? A.ref : A.tgt)[(size_t)rr * W + col] : 0u;
-        }
-    };
-    auto stage_commit = [&](int buf, const uint32_t (&v)[2], const bool (&in)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = tid + q * nthr;
-            if (k < nstage) {
-                const bool isRef = k < nL4;
-                (isRef ? refS0 + buf * nL4 : tgtS0 + buf * nT4)[isRef ? k : k - nL4] = in[q] ? gsw_pix(v[q], 1.f, A.fMax) : gsw_pix(0u, 0.f, 0.f);
-            }
-        }
-    };
-    // weights and e tile of image row rr (its pixels are in staging buffer `buf`) into weight buffer / e tile `buf`
-    auto build = [&](int rr, int buf) {
-        int tb = threadIdx.x;
-        asm volatile("" : "+v"(tb));            // nothing of a build stays live across the taps
-        gsw_build_weights(A, tb, nthr, rr, y0, ny, x0, TYS, refS0 + buf * nL4, cenS, wS0 + buf * wfl);
-        gsw_build_e(g, tb, nthr, right, refS0 + buf * nL4, tgtS0 + buf * nT4, eT0 + buf * efl);
-    };
-    auto taps = [&](int rr, int buf) {
-        if (!active) return;
-        bool use[TY];
-#pragma unroll
-        for (int t = 0; t < TY; ++t) use[t] = TY * grp + t < ny && (unsigned)(rr - (yg + t) + p) < (unsigned)win;
-        const float *const wG = wS0 + buf * wfl + (TY * grp) * win * Tx, *const eT = eT0 + buf * efl;
-        if (use[0] && use[1]) gsw_row_taps<2, RD, 0, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
-        else if (use[0]) gsw_row_taps<2, RD, 0, 1>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
-        else if (use[1]) gsw_row_taps<2, RD, 1, 2>(cost, wG, eT, win, Tx, xg, dg, Ses, emask);
-    };
-
-    // ---- prologue: row r_lo staged and built, row r_lo + 1 staged (not overlapped: 1 / (win + TYS - 1) of the work)
-    {
-        uint32_t v[2]; bool in[2];
-        stage_issue(r_lo, v, in);
-        stage_commit(0, v, in);
-        if (r_lo < r_hi) { stage_issue(r_lo + 1, v, in); stage_commit(1, v, in); }
-    }
-    __syncthreads();                            // centre pixels and the staged rows visible
-    build(r_lo, 0);
-
-    for (int r = r_lo; r <= r_hi; ++r) {
-        __syncthreads();                        // buffers of row r complete, row r + 1 staged; everyone is done with row r - 1
-        const int b = (r - r_lo) & 1;
-        uint32_t sv[2]; bool sin[2];
-        const bool more = r + 1 <= r_hi, more2 = r + 2 <= r_hi;
-        if (more2) stage_issue(r + 2, sv, sin);
-        if (phase == 0 && more) build(r + 1, b ^ 1);
-        taps(r, b);
-        if (phase != 0 && more) build(r + 1, b ^ 1);
-        if (more2) stage_commit(b, sv, sin);     // staging buffer b held row r: read by build(r) in the previous iteration
-    }
-
-    // ---- winner-take-all over this chunk's candidates, as gsw_aggregate_kernel
-    if (active) {
-#pragma unroll
-        for (int t = 0; t < TY; ++t) {
-            if (TY * grp + t >= ny) continue;
-#pragma unroll
-            for (int xi = 0; xi < GSW_RX; ++xi) {
-                const int x = x0 + GSW_RX * xg + xi;
-                u64 bk = KEY_NONE;
-#pragma unroll
-                for (int di = 0; di < RD; ++di) {
-                    const int d = dlo + RD * dg + di;
-                    const bool valid = (x < W) && (d <= A.maxD) && (right ? (x + d <= W - 1) : (x - d >= 0));
-                    if (valid) bk = min(bk, make_key(cost[t][xi][di], right ? (uint32_t)(x + d) : (uint32_t)d));
-                }
-                if (bk != KEY_NONE) atomicMin(&best[(TY * grp + t) * Tx + GSW_RX * xg + xi], bk);
             }
         }
     }

@@ -69,6 +69,7 @@ struct Tuning {
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
     int evol_fail = 0;                // test hook: 1 = the TAD volume's allocation really fails (a hipMalloc no device can serve)
+    int asw_tail = -1;                // -1: the host decides; 0: never split the last partial round of workgroups into half-width tiles; 1: whenever possible
 };
 std::mutex g_tune_mutex;
 std::atomic<unsigned> g_tune_version{1};
@@ -95,6 +96,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ALT_QUEUE_CAP") t.alt_queue_cap = v ? std::max(1, atoi(v)) : 0;
     else if (name == "SSAMD_AUTOTUNE") t.autotune_env = v ? (atoi(v) > 0 ? 1 : (atoi(v) < 0 ? -1 : 0)) : -2;
     else if (name == "SSAMD_ASW_EVOL_FAIL") t.evol_fail = num(0);
+    else if (name == "SSAMD_ASW_TAIL") t.asw_tail = num(-1);
     else return false;
     return true;
 }
@@ -102,7 +104,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
-                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL"};
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -227,6 +229,7 @@ struct Ctx {
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
     int evol_small_calls = 0;           // consecutive calls that needed less than a quarter of the TAD volume's capacity
     long long evol_fallbacks = 0;       // calls that ran without the volume (in-kernel e tiles) or off the wave kernel for lack of memory
+    long long tail_splits = 0;          // phase-shifted launches whose last partial round of workgroups ran as half-width tiles
     Profile prof;
 };
 
@@ -964,7 +967,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 return SSAMD_OK;
             }
             const int xt = (W + Tx - 1) / Tx;
-            const int evolW = round_up(xt * Tx + 2 * p, 4);           // rows stay 16-byte aligned for any Se
+            // rows stay 16-byte aligned for any Se; the phase-shifted kernel's half-width tail tiles (see launch) may reach
+            // up to half a tile + 4 columns further than the last full tile
+            const int evolW = round_up(xt * Tx + 2 * p + (g.wave_rx ? 0 : Tx / 2 + 8), 4);
             const size_t bytes = (size_t)chunks * (size_t)(r1 - r0) * (size_t)evolW * (size_t)Se;
             // A buffer four times larger than the calls need is given back -- but only after eight such calls in a row
             // and never between the trial launches of the autotuner: a workload alternating a large and a small shape
@@ -1061,8 +1066,46 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                     else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = asw_aggregate_pipe_kernel<false, 216, 284, 80>;
                 }
                 if (int grc = grant_dyn_lds(c, (const void *)pk, g.lds_bytes)) return grc;
-                hipLaunchKernelGGL(pk, grid, block, g.lds_bytes, s, a);
+                // The last PARTIAL round of workgroups (round 4).  The kernel keeps one 12-wave workgroup per CU, so a launch
+                // of n workgroups takes ceil(n / 256) rounds: a row strip of an 8-GPU run (135 rows x 16 tiles = 8.44 rounds)
+                // pays nine.  When the last round is at most half full, the rows that fill whole rounds keep the tile and the
+                // remaining rows are launched with tiles of half the columns (twice the workgroups, half the taps each: the
+                // round ends after about half its time).  Same taps in the same order per (x, d): maps cannot change
+                // (tests/test_gpu_asw.py).  Worth ~4 % at 8.44 rounds, nothing beyond a few dozen; SSAMD_ASW_TAIL=0 / 1 forces.
+                int rows_main = grows;
+                AswGeom tail_g;
+                if (!alternate && tune().asw_tail != 0 && g.XG >= 4) {
+                    const long long per_row = (long long)grid.x * g.nchunks, n = per_row * grows, slots = 256;
+                    const long long full = n / slots, rem = n - full * slots;
+                    if (full >= 1 && rem > 0 && 2 * rem <= slots && (full < 32 || tune().asw_tail > 0)) {
+                        const int rm = (int)(full * slots / per_row);
+                        if (rm >= 1 && rm < grows &&
+                            asw_layout_e(tail_g, win, (g.XG + 1) / 2, g.DG, 160 * 1024, g.JC, 8, true, false, true) && tail_g.pipe &&
+                            tail_g.Se == g.Se && tail_g.Dc == g.Dc &&
+                            (a.evol == nullptr || round_up(((W + tail_g.Tx - 1) / tail_g.Tx) * tail_g.Tx + 2 * p, 4) <= a.evolW)) {
+                            tail_g.nchunks = g.nchunks;
+                            rows_main = rm;
+                        }
+                    }
+                }
+                hipLaunchKernelGGL(pk, dim3(grid.x, rows_main, grid.z), block, g.lds_bytes, s, a);
                 HIP_TRY(hipGetLastError());
+                if (rows_main < grows) {
+                    ++c.tail_splits;
+                    AswArgs t = a;
+                    const size_t skip = (size_t)rows_main * W;
+                    t.g = tail_g;
+                    t.row0 = row0 + rows_main; t.rows = rows - rows_main;
+                    if (t.disp) t.disp += skip;
+                    if (t.keyL) t.keyL += skip;
+                    if (t.keyR) t.keyR += skip;
+                    if (t.costs) t.costs += skip * (size_t)nD;
+                    auto tk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
+                    if (int grc = grant_dyn_lds(c, (const void *)tk, tail_g.lds_bytes)) return grc;
+                    hipLaunchKernelGGL(tk, dim3((W + tail_g.Tx - 1) / tail_g.Tx, grows - rows_main, tail_g.nchunks), dim3(tail_g.threads),
+                                       tail_g.lds_bytes, s, t);
+                    HIP_TRY(hipGetLastError());
+                }
                 return SSAMD_OK;
             }
             auto kern = chunked ? (d_costs ? asw_aggregate_kernel<true, true> : asw_aggregate_kernel<false, true>)
@@ -1083,8 +1126,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             // first launches after an idle period, so timing the candidates one after the other would favour the
             // late ones
             std::vector<float> cand_ms(trial.size(), 3.0e38f);
-            for (const AswGeom &g : trial)                                                // code load, clocks, scratch
-                if (prepare_evol(g) == SSAMD_OK) (void)launch(g);                        // (a wave candidate whose volume cannot be had is never launched)
+            bool all_prepared = true;     // a candidate whose volume cannot be had right now is never launched, and the verdict of such a round is not cached
+            for (const AswGeom &g : trial) {                                             // code load, clocks, scratch
+                if (prepare_evol(g) == SSAMD_OK) (void)launch(g);
+                else all_prepared = false;
+            }
             for (int round = 0; round < 4; ++round)
                 for (size_t ci = 0; ci < trial.size(); ++ci) {
                     float ms = 3.0e38f;
@@ -1100,10 +1146,12 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 if (cand_ms[ci] < best_ms * (ci == 0 ? 1.0f : 0.985f)) { best_ms = cand_ms[ci]; fastest = trial[ci]; }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
-            {
+            if (all_prepared) {
                 std::lock_guard<std::mutex> glk(g_geom_mutex);
                 g_asw_geom_cache[shape] = fastest;
                 g_asw_geom_tuned[shape] = true;
+            } else {
+                g_err.clear();
             }
             a.g = fastest;
         }
@@ -1169,10 +1217,10 @@ int asw_alternate_rows(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int 
 }
 
 // ------------------------------------------------------------ GSW
-bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int Hy = 1, int pipe = 0)
+bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int Hy = 1)
 {
     const int p = win / 2;
-    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = 8 / Ty; g.Hy = Hy; g.pipe = pipe;       // thread tile: Ty rows x 4 columns x 8 / Ty disparities = 32 accumulators
+    g.XG = XG; g.DG = DG; g.Ty = Ty; g.Rd = Ty == 2 ? 4 : 8; g.Hy = Hy;
     g.Tx = GSW_RX * XG; g.Dc = g.Rd * DG;
     g.threads = round_up(XG * DG, 64);
     g.nL = g.Tx + 2 * p;
@@ -1185,18 +1233,14 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int H
     g.emask = std::min(P, 32) - 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
-    const int nbuf = pipe ? 2 : 1;                     // phase-shifted kernel: weights and e tile of image row r + 1 next to those of row r
-    g.off_w = take((size_t)nbuf * Ty * Hy * win * g.Tx * 4);
+    g.off_w = take((size_t)Ty * Hy * win * g.Tx * 4);
     const int nL4 = round_up(g.nL, 4);                 // the e tasks cover 4 columns
-    g.off_e = take((size_t)nbuf * nL4 * g.Se * 4);
+    g.off_e = take((size_t)nL4 * g.Se * 4);
     g.off_ref = take((size_t)nL4 * 16 * 2);            // pixel staging is double-buffered (prefetch of the next image row)
     g.off_tgt = take((size_t)(g.nT + nL4 - g.nL) * 16 * 2);
     g.off_best = take((size_t)Ty * Hy * g.Tx * 8);
     g.off_cen = take((size_t)Ty * Hy * g.Tx * 4);
     g.lds_bytes = (int)off;
-    if (pipe)       // two-row thread tiles; a thread stages at most two pixels per image row
-        return off <= limit && Ty == 2 && g.threads * Hy <= GSW_PIPE_MAX_THREADS && g.threads <= GSW_MAX_THREADS &&
-               nL4 + g.nT + nL4 - g.nL <= 2 * g.threads * Hy;
     return off <= limit && g.threads * Hy <= GSW_MAX_THREADS;
 }
 
@@ -1225,9 +1269,9 @@ int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
 {
     if (!tune().gsw_geom.empty()) {                             // experiment hook: "XG,DG,Ty"
         const char *const env = tune().gsw_geom.c_str();
-        int XG = 0, DG = 0, Ty = 1, Hy = 1, pipe = 0;              // "XG,DG[,Ty[,Hy[,pipe]]]"
-        if (sscanf(env, "%d,%d,%d,%d,%d", &XG, &DG, &Ty, &Hy, &pipe) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2 || Ty == 4) && Hy >= 1 && Hy <= 8 &&
-            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024, Hy, pipe ? 1 : 0)) {
+        int XG = 0, DG = 0, Ty = 1, Hy = 1;                       // "XG,DG[,Ty[,Hy]]"
+        if (sscanf(env, "%d,%d,%d,%d", &XG, &DG, &Ty, &Hy) >= 2 && XG >= 1 && DG >= 1 && (Ty == 1 || Ty == 2) && Hy >= 1 && Hy <= 8 &&
+            XG * DG <= GSW_MAX_THREADS && gsw_layout(best, win, XG, DG, Ty, 160 * 1024, Hy)) {
             best.nchunks = (nD + best.Dc - 1) / best.Dc;
             return SSAMD_OK;
         }
@@ -1344,7 +1388,7 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.iterations = iterations; a.fMax = fMax;
         const int TyS = a.g.Ty * a.g.Hy;
         const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + TyS - 1) / TyS, a.g.nchunks), block(a.g.threads * a.g.Hy);
-        auto kernel = a.g.pipe ? gsw_aggregate_pipe_kernel<4> : a.g.Ty == 4 ? gsw_aggregate_kernel<4, 2> : a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
+        auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
         if ((rc = grant_dyn_lds(c, (const void *)kernel, a.g.lds_bytes))) return rc;
         for (int pass = 0; pass < 2; ++pass) {
             a.right = pass;
@@ -1549,6 +1593,7 @@ int ssamd_counter(int device, const char *name, long long *value)
     const std::string n(name);
     if (n == "evol_fallbacks") *value = c->evol_fallbacks;
     else if (n == "evol_bytes") *value = (long long)c->evol.cap;
+    else if (n == "tail_splits") *value = c->tail_splits;
     else return fail(SSAMD_EINVAL, "unknown counter %s", name);
     return SSAMD_OK;
 }

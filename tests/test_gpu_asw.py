@@ -416,12 +416,53 @@ def test_asw_when_the_tad_volume_allocation_really_fails(ss):
         got = m.compute(tL, tR)
         assert torch.equal(got, want)
         assert _native.counter("evol_fallbacks") == n0 + 1
-        # the small-range wave kernel cannot run without its volume: a clean error, no stale HIP error afterwards
-        with pytest.raises(_native.NativeError):
-            ss.passive.StereoASW(winSize=35, maxDisparity=16).compute(tL, tR)
+        # the small-range wave kernel cannot run without its volume: with autotuning off that is a clean error (and no stale
+        # HIP error afterwards); a first call of a shape under the tuner simply ends up on a workgroup candidate
+        small = ss.passive.StereoASW(winSize=35, maxDisparity=16)
+        prev = _native.lib().ssamd_autotune(0)
+        try:
+            with pytest.raises(_native.NativeError):
+                small.compute(tL, tR)
+        finally:
+            _native.lib().ssamd_autotune(prev)
+        tuned = small.compute(tL, tR)
+    assert torch.equal(small.compute(tL, tR), tuned)          # same map from the wave kernel once the volume can be had again
     assert torch.equal(m.compute(tL, tR), want)
     assert _native.counter("evol_fallbacks") == n0 + 1 and _native.counter("evol_bytes") > 0
     assert ss.passive.StereoASW(winSize=35, maxDisparity=16).compute(tL, tR).shape == (40, 300)
+
+
+@pytest.mark.parametrize("shape,maxd,consistent,force", [((135, 1920), 192, False, None), ((135, 1920), 192, True, None),
+                                                         ((37, 700), 70, False, "1"), ((37, 700), 70, True, "1")])
+def test_asw_half_width_tiles_for_the_last_partial_round(shape, maxd, consistent, force, ss):
+    """a launch whose last round of workgroups is at most half full (the 135-row strip of an 8-GPU run of config 3: 8.44
+    rounds) runs the rows of that round with tiles of half the columns: same maps, same raw costs as one geometry for all rows"""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    H, W = shape
+    L, R, _ = make_pair(H, W, maxd, 21)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(winSize=35, maxDisparity=maxd, consistent=consistent)
+
+    def costs():
+        c = np.empty((H, W, maxd + 1), np.float32)
+        _native.check(_native.lib().ssamd_asw_costs(L.ctypes.data, R.ctypes.data, H, W, 35, maxd, 0, 5.0, 17.5, c.ctypes.data, -1))
+        return c
+    with _native.options(SSAMD_ASW_TAIL="0", SSAMD_AUTOTUNE="0"):
+        n0 = _native.counter("tail_splits")
+        want = m.compute(tL, tR)
+        cw = costs() if not consistent else None
+        assert _native.counter("tail_splits") == n0
+    opts = dict(SSAMD_AUTOTUNE="0")
+    if force:
+        opts["SSAMD_ASW_TAIL"] = force
+    with _native.options(**opts):
+        n0 = _native.counter("tail_splits")
+        got = m.compute(tL, tR)
+        assert _native.counter("tail_splits") == n0 + 1, "the split did not happen: the test does not test it"
+        if cw is not None:
+            assert np.array_equal(costs(), cw, equal_nan=True)
+    assert torch.equal(got, want)
 
 
 def test_tad_volume_is_not_released_on_every_switch_of_shape(ss):
