@@ -35,9 +35,15 @@ __device__ __forceinline__ void asw_row_unpack6(AswRow6 &row, const uint2 packed
 }
 
 // KM: build rounds known at compile time (3 for the class default), 0: counted at run time
-template <bool WITH_COSTS, int KM>
-__global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWaveArgs A)
+// OCC: waves per SIMD the register allocation aims at.  3 (round 3): up to 168 VGPRs, all reads of a build in flight.  4 (round 4):
+// 128 VGPRs -- the 96 registers of accumulators and e window leave 32 for everything else, so the build takes its rounds one after
+// the other (12 instead of 36 registers in flight) and a few values of the row prologue live in scratch; pays when the wave's LDS
+// slice lets a fourth wave per SIMD be resident (AswWaveGeom::Se = 24).
+// CREG: window centres in registers (see asw_aggregate_wave_kernel): no cen array in LDS, two instead of three reads per weight pair.
+template <bool WITH_COSTS, int KM, int OCC = 3, bool CREG = false>
+__global__ __launch_bounds__(256, OCC) void asw_aggregate_wave6_kernel(const AswWaveArgs A)
 {
+    static_assert(!CREG || KM > 0, "register centres need the straight-line build");
     constexpr int RX = 4, RD = 6, NWR = 10;          // nine right weights used, read as five pairs
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const AswWaveGeom &g = A.g;
@@ -74,15 +80,30 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
     for (int a = 0; a < RX; ++a)
 #pragma unroll
         for (int b = 0; b < RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
-    for (int c = lane; c < ncen; c += 64) {                      // window centres (row y)
-        const bool isL = c < Txw;
-        const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)ccol < (unsigned)W) {
-            const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
-            v = make_float4(q.L, q.a, q.b, 1.f);
+    float cenx[CREG ? KM : 1], ceny[CREG ? KM : 1], cenz[CREG ? KM : 1];      // CREG: Lab of the centres lane, lane + 64, ... (row y)
+    if constexpr (CREG) {
+#pragma unroll
+        for (int r = 0; r < KM; ++r) {
+            const int c = 64 * r + lane;
+            const bool isL = c < Txw;
+            const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
+            cenx[r] = ceny[r] = cenz[r] = 0.f;
+            if (c < ncen && (unsigned)ccol < (unsigned)W) {
+                const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+                cenx[r] = q.L; ceny[r] = q.a; cenz[r] = q.b;
+            }
         }
-        cenLab[c] = v;
+    } else {
+        for (int c = lane; c < ncen; c += 64) {                  // window centres (row y)
+            const bool isL = c < Txw;
+            const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)ccol < (unsigned)W) {
+                const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+                v = make_float4(q.L, q.a, q.b, 1.f);
+            }
+            cenLab[c] = v;
+        }
     }
     // merged support-weight build of two tap columns (j, j + 1): see asw_aggregate_wave_kernel
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -107,8 +128,37 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
         uint32_t tap_b = sbase + g.off_pixL + 16 * j, cen_b = sbase + g.off_cen, dst_b = sbase + g.off_w;
         asm volatile("" : "+s"(tap_b), "+s"(cen_b), "+s"(dst_b));
         const uint32_t row1 = (uint32_t)wrow * 4;
+        if constexpr (CREG) {
+            const uint32_t da = dst_b + lane4, db_ = da + row1;
+            float4 ta_[KM], tb[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                const uint32_t ta = tap_b + tapoff[r];
+                ta_[r] = ld4(ta); tb[r] = ld4(ta + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) asm volatile("" ::"v"(ta_[r].w), "v"(tb[r].w) : "memory");
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                const float4 ce = make_float4(cenx[r], ceny[r], cenz[r], 0.f);
+                *(lds_f1)(da + 256 * r) = weight(ce, ta_[r], pj0);
+                *(lds_f1)(db_ + 256 * r) = weight(ce, tb[r], pj1);
+            }
+            return;
+        }
         if constexpr (KM > 0) {
             const uint32_t ca = cen_b + lane16, da = dst_b + lane4, db_ = da + row1;
+            if constexpr (OCC >= 4) {
+#pragma unroll
+                for (int r = 0; r < KM; ++r) {
+                    const uint32_t ta = tap_b + tapoff[r];
+                    const float4 ce0 = ld4(ca + 1024 * r), ta0 = ld4(ta), tb0 = ld4(ta + 16);
+                    asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w) : "memory");
+                    *(lds_f1)(da + 256 * r) = weight(ce0, ta0, pj0);
+                    *(lds_f1)(db_ + 256 * r) = weight(ce0, tb0, pj1);
+                }
+                return;
+            }
             float4 ce[KM], ta_[KM], tb[KM];
 #pragma unroll
             for (int r = 0; r < KM; ++r) {
@@ -163,7 +213,8 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
         }
         asw_wave_sync();
         // e window: rows ul = RX xg + n of the tile, 8-byte slot dg
-        const unsigned char *erow = eT + (RX * xg) * Se + 8 * dg;
+        // (lanes past the last column group -- lane 63 of the 21 x 3 class-default strip -- read the last group's e rows: the tile has no slack behind it)
+        const unsigned char *erow = eT + (RX * min(xg, g.NXG - 1)) * Se + 8 * dg;
         AswRow6 ew[RX];
 #pragma unroll
         for (int n = 0; n < RX - 1; ++n) {

@@ -32,6 +32,7 @@ struct AswWaveGeom {
     int waves;                              // waves per workgroup
     int merged, K;                          // round 3: left and right centres in ONE list of K = ceil((Txw + nRcw) / 64) build rounds
     int RD;                                 // disparities per lane: 4, or 6 (asw_wave6_kernel.hip.h: 8-byte e slots, Se = 8 * odd)
+    int creg;                               // round 4: 1 = the window centres live in registers (no cen array in LDS; straight-line merged build only)
     int off_w, off_cen, off_pixL, off_pixR, off_e, off_bestL, off_bestR;     // offsets inside a wave's LDS slice
     int wave_lds;                           // bytes of LDS per wave
 };
@@ -85,9 +86,14 @@ __device__ __forceinline__ void asw_wave_order()
 // last rounds (class default D 0..16, 4-column tile: 48 + 67 centres = 2 rounds instead of 1 + 2).  The two parts
 // read different pixel rows; pixR follows pixL in LDS, so the tap address of list entry c is
 // pixL + 16 (c + j) + (c < Txw ? 0 : 32 pad): one per-lane constant per round (tapoff), set up once per wave.
-template <bool WITH_COSTS, int RX, int KL = 0, int KR = 0, int KM = 0>
+// CREG (round 4, with KM > 0): the centres a lane evaluates are the SAME in every build of the kernel (list entries lane,
+// lane + 64, ...), so their Lab values are loaded once from the records into 3 KM registers instead of being kept in an LDS
+// array and re-read twice per tap-column pair: a third fewer LDS reads per weight, and the wave's LDS slice loses 16 bytes
+// per centre -- at D 0..7 / win 35 (124-column strips, 255 centres) that is 13.9 -> 9.9 KB, 11 -> 16 resident waves per CU.
+template <bool WITH_COSTS, int RX, int KL = 0, int KR = 0, int KM = 0, bool CREG = false>
 __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) void asw_aggregate_wave_kernel(const AswWaveArgs A)
 {
+    static_assert(!CREG || KM > 0, "register centres need the straight-line merged build");
     constexpr int NWR = asw_nwr(RX);
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const AswWaveGeom &g = A.g;
@@ -124,15 +130,30 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
     for (int a = 0; a < RX; ++a)
 #pragma unroll
         for (int b = 0; b < ASW_RD; ++b) { accN[a][b] = 0.f; accS[a][b] = 0.f; }
-    for (int c = lane; c < ncen; c += 64) {                      // window centres (row y)
-        const bool isL = c < Txw;
-        const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)ccol < (unsigned)W) {
-            const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
-            v = make_float4(q.L, q.a, q.b, 1.f);
+    float cenx[CREG ? KM : 1], ceny[CREG ? KM : 1], cenz[CREG ? KM : 1];      // CREG: Lab of the centres lane, lane + 64, ... (row y)
+    if constexpr (CREG) {
+#pragma unroll
+        for (int r = 0; r < KM; ++r) {
+            const int c = 64 * r + lane;
+            const bool isL = c < Txw;
+            const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
+            cenx[r] = ceny[r] = cenz[r] = 0.f;
+            if (c < ncen && (unsigned)ccol < (unsigned)W) {
+                const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+                cenx[r] = q.L; ceny[r] = q.a; cenz[r] = q.b;
+            }
         }
-        cenLab[c] = v;
+    } else {
+        for (int c = lane; c < ncen; c += 64) {                  // window centres (row y)
+            const bool isL = c < Txw;
+            const int ccol = isL ? x0 + c : xrc_lo + (c - Txw);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)ccol < (unsigned)W) {
+                const PixRec q = (isL ? A.recL : A.recR)[(size_t)y * W + ccol];
+                v = make_float4(q.L, q.a, q.b, 1.f);
+            }
+            cenLab[c] = v;
+        }
     }
     // Support weights of one tap column: lane l evaluates the centres l, l + 64, ... of the left and of the right part.
     // A tap column outside the image has L = +inf and so a zero weight; centres outside the image only feed candidates
@@ -213,6 +234,24 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
     auto build_merged = [&](uint32_t tap_b, uint32_t cen_b, uint32_t dst_b, float pj0, float pj1) {
         asm volatile("" : "+s"(tap_b), "+s"(cen_b), "+s"(dst_b));
         const uint32_t row1 = (uint32_t)wrow * 4;
+        if constexpr (CREG) {                            // centres in registers: two tap reads per weight pair, all in flight together
+            const uint32_t da = dst_b + lane4, db_ = da + row1;
+            float4 ta_[KM], tb[KM];
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                const uint32_t ta = tap_b + tapoff[r];
+                ta_[r] = ld4(ta); tb[r] = ld4(ta + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < KM; ++r) asm volatile("" ::"v"(ta_[r].w), "v"(tb[r].w) : "memory");
+#pragma unroll
+            for (int r = 0; r < KM; ++r) {
+                const float4 ce = make_float4(cenx[r], ceny[r], cenz[r], 0.f);
+                *(lds_f1)(da + 256 * r) = weight(ce, ta_[r], pj0);
+                *(lds_f1)(db_ + 256 * r) = weight(ce, tb[r], pj1);
+            }
+            return;
+        }
         if constexpr (KM > 0) {
             const uint32_t ca = cen_b + lane16, da = dst_b + lane4, db_ = da + row1;
             if constexpr (RX == 4 && KM <= 3) {          // registers to spare: all reads of the build in flight together

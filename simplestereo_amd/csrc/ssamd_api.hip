@@ -69,6 +69,8 @@ struct Tuning {
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
     int evol_fail = 0;                // test hook: 1 = the TAD volume's allocation really fails (a hipMalloc no device can serve)
+    int wave_creg = 1;                // 0: the wave kernel keeps its window centres in LDS (round-3 form)
+    int wave6_occ = 0, wave6_se = 0;  // 0: the host decides; 3 / 4: waves per SIMD the six-per-lane wave kernel is compiled for; 24 / 40: bytes per e column
     int asw_tail = -1;                // -1: the host decides; 0: never split the last partial round of workgroups into half-width tiles; 1: whenever possible
 };
 std::mutex g_tune_mutex;
@@ -97,6 +99,9 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_AUTOTUNE") t.autotune_env = v ? (atoi(v) > 0 ? 1 : (atoi(v) < 0 ? -1 : 0)) : -2;
     else if (name == "SSAMD_ASW_EVOL_FAIL") t.evol_fail = num(0);
     else if (name == "SSAMD_ASW_TAIL") t.asw_tail = num(-1);
+    else if (name == "SSAMD_ASW_WAVE_CREG") t.wave_creg = num(1);
+    else if (name == "SSAMD_ASW_WAVE6_OCC") t.wave6_occ = num(0);
+    else if (name == "SSAMD_ASW_WAVE6_SE") t.wave6_se = num(0);
     else return false;
     return true;
 }
@@ -104,7 +109,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
-                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL"};
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE6_OCC", "SSAMD_ASW_WAVE6_SE", "SSAMD_ASW_WAVE_CREG"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -492,10 +497,11 @@ void asw_try_pipe(AswGeom &g, int win)
 // slice of LDS.  false: the range does not fit one chunk of at most ASW_WAVE_MAX_DG disparity groups.
 static constexpr int ASW_WAVE_MAX_DG = 16;
 // One candidate strip: nxg column groups, left / right centres in separate build rounds or merged into one list.
-bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool merged, int rd = ASW_RD)
+bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool merged, int rd = ASW_RD, bool creg = false)
 {
     g.RX = rx;
     g.RD = rd;
+    g.creg = 0;
     const int p = win / 2;
     g.DG = DG;
     g.NXG = nxg;
@@ -520,6 +526,7 @@ bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool 
     // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
     // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
     g.Se = rd == 6 ? 8 * ((g.DG + 1) | 1) : 4 * (g.DG | 1);        // (six per lane: 8-byte slots, an odd number of them and one to spare)
+    if (rd == 6 && tune().wave6_se == 24) g.Se = 8 * g.DG;          // round 4: no spare slot (a smaller LDS slice per wave: more resident waves)
     g.waves = tune().wave_wg ? tune().wave_wg : 1;
     // order matters: the build's last round reads up to 127 entries past the end of the centres and of each pixel
     // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile -- and the merged build
@@ -527,10 +534,15 @@ bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return (int)o; };
     g.off_w = take((size_t)(g.SLw + g.SRw) * 4 * 2);        // two rows: tap columns j and j + 1
-    g.off_cen = take((size_t)(g.Txw + g.nRcw) * 16);
+    // centres in registers (asw_aggregate_wave_kernel<..., CREG>): four-per-lane, 4-column tile, merged build of at most four rounds
+    g.creg = creg && merged && rx == 4 && g.K >= 2 && (rd == 6 ? g.K <= 3 : g.K <= 4) ? 1 : 0;      // (the instantiations that exist)
+    g.off_cen = take(g.creg ? 0 : (size_t)(g.Txw + g.nRcw) * 16);
     g.off_pixL = take((size_t)g.nLw * 16);
     g.off_pixR = take((size_t)g.nRw * 16);
-    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(129 + 2 * p) * 16) + (size_t)rx * g.Se);
+    // (+ rx e columns of slack: the lanes past the last column group read inside the slice.  The six-per-lane kernel clamps
+    //  their column group instead, round 4: LDS is granted in 512-byte granules, and at win 35 those 160 bytes decide whether
+    //  11 or 12 of its waves are resident per CU -- 13 424 -> 13 264 bytes, 6.06 -> 5.8 ms at 1080p / D 0..16)
+    g.off_e = take(std::max((size_t)g.nLw * g.Se, (size_t)(129 + 2 * p) * 16) + (rd == 6 ? 0 : (size_t)rx * g.Se));
     // the winner arrays are only used after the last window row: they share the pixel rows' space
     g.off_bestL = g.off_pixL;
     g.off_bestR = g.off_pixL + (int)(((size_t)g.Txw * 8 + 15) & ~(size_t)15);
@@ -544,10 +556,11 @@ bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool 
 // K build rounds (~17 issue slots each: one weight per lane) + the taps (~59 slots with the 4-column tile, ~110 with
 // the 8-column one).  SSAMD_ASW_WAVE_MERGE=0 restores the round-2 form (all column groups, separate rounds).
 // rx: 8 or 4 columns per lane; 4 | 16 (= 20, an autotuning candidate, AswGeom::wave_rx): 4 columns and never six disparities per lane
-bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
+bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx, bool creg = false)
 {
     const bool never6 = (rx & 16) != 0;
     rx &= 15;
+    creg = creg && tune().wave_creg != 0;
     const int DG = (nD + ASW_RD - 1) / ASW_RD;
     if (DG < 1 || DG > ASW_WAVE_MAX_DG) return false;
     const int nxg_max = 64 / DG;
@@ -562,7 +575,7 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
         for (int merged = 0; merged <= 1; ++merged) {
             AswWaveGeom c;
             if (merged && nxg != nxg_max && tune().wave_merge == 2) continue;
-            if (!asw_wave_layout_one(c, win, DG, rx, nxg, merged != 0)) continue;
+            if (!asw_wave_layout_one(c, win, DG, rx, nxg, merged != 0, ASW_RD, creg)) continue;
             if (merged && c.K > 4) continue;
             if (!merged && nxg != nxg_max) continue;     // fewer column groups only pay through a saved merged round
             const double cost = (c.K * c_round + c_taps) / (double)c.Txw;
@@ -577,7 +590,7 @@ bool asw_wave_layout(AswWaveGeom &g, int win, int nD, int rx)
             const int nxg6 = 64 / DG6;
             for (int nxg = nxg6; nxg >= std::max(1, nxg6 - 4); --nxg) {
                 AswWaveGeom c;
-                if (!asw_wave_layout_one(c, win, DG6, 4, nxg, true, 6) || c.K > 4) continue;
+                if (!asw_wave_layout_one(c, win, DG6, 4, nxg, true, 6, creg) || c.K > 4) continue;
                 const double cost = (c.K * c_round + 87.0) / (double)c.Txw;
                 if (cost < 0.95 * best) { best = cost / 0.95; g = c; }
             }
@@ -638,7 +651,8 @@ bool asw_geometry_forced()
 {
     const Tuning &t = tune();
     return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
-           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0 || t.wave_rd != 0;
+           t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0 || t.wave_rd != 0 ||
+           t.wave6_occ != 0 || t.wave6_se != 0 || t.wave_creg != 1;
 }
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
@@ -961,7 +975,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.evol = nullptr;
             int chunks = g.nchunks, Tx = g.Tx, Dc = g.Dc, Se = g.Se;
             if (g.wave_rx) {
-                if (!asw_wave_layout(wa.g, win, nD, g.wave_rx)) return fail(SSAMD_ELIMIT, "wave kernel geometry does not fit LDS");
+                if (!asw_wave_layout(wa.g, win, nD, g.wave_rx, !d_costs && tune().wave_unroll != 0))
+                    return fail(SSAMD_ELIMIT, "wave kernel geometry does not fit LDS");
                 chunks = 1; Tx = wa.g.Txw; Dc = wa.g.Dc; Se = wa.g.Se;
             } else if (!g.pipe || tune().asw_evol == 0) {
                 return SSAMD_OK;
@@ -1030,13 +1045,16 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 const bool unrolled = tune().wave_unroll != 0;
                 if (wa.g.RD == 6) {                                                         // six disparities per lane
                     wk = d_costs ? asw_aggregate_wave6_kernel<true, 0> : asw_aggregate_wave6_kernel<false, 0>;
-                    if (unrolled && !d_costs && wa.g.K == 3) wk = asw_aggregate_wave6_kernel<false, 3>;
-                    else if (unrolled && !d_costs && wa.g.K == 2) wk = asw_aggregate_wave6_kernel<false, 2>;
+                    const bool occ4 = tune().wave6_occ == 4;
+                    if (unrolled && !d_costs && wa.g.K == 3)
+                        wk = wa.g.creg ? asw_aggregate_wave6_kernel<false, 3, 3, true> : occ4 ? asw_aggregate_wave6_kernel<false, 3, 4> : asw_aggregate_wave6_kernel<false, 3>;
+                    else if (unrolled && !d_costs && wa.g.K == 2)
+                        wk = wa.g.creg ? asw_aggregate_wave6_kernel<false, 2, 3, true> : occ4 ? asw_aggregate_wave6_kernel<false, 2, 4> : asw_aggregate_wave6_kernel<false, 2>;
                 } else if (unrolled && !d_costs && wa.g.merged) {
                     const int key = wa.g.RX * 10 + wa.g.K;                                  // merged build, K rounds
-                    if (key == 42) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 2>;        // class default D 0..16: 48 + 67 centres
-                    else if (key == 43) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 3>;
-                    else if (key == 44) wk = asw_aggregate_wave_kernel<false, 4, 0, 0, 4>;
+                    if (key == 42) wk = wa.g.creg ? asw_aggregate_wave_kernel<false, 4, 0, 0, 2, true> : asw_aggregate_wave_kernel<false, 4, 0, 0, 2>;   // class default D 0..16 four per lane: 48 + 67 centres
+                    else if (key == 43) wk = wa.g.creg ? asw_aggregate_wave_kernel<false, 4, 0, 0, 3, true> : asw_aggregate_wave_kernel<false, 4, 0, 0, 3>;
+                    else if (key == 44) wk = wa.g.creg ? asw_aggregate_wave_kernel<false, 4, 0, 0, 4, true> : asw_aggregate_wave_kernel<false, 4, 0, 0, 4>;
                     else if (key == 82) wk = asw_aggregate_wave_kernel<false, 8, 0, 0, 2>;
                     else if (key == 83) wk = asw_aggregate_wave_kernel<false, 8, 0, 0, 3>;
                     else if (key == 84) wk = asw_aggregate_wave_kernel<false, 8, 0, 0, 4>;
@@ -1615,7 +1633,7 @@ int ssamd_asw_geometry(int width, int rows, int winSize, int maxDisparity, int m
     out[0] = g.Tx; out[1] = g.Dc; out[2] = g.nchunks; out[3] = g.threads; out[4] = g.lds_bytes;
     out[5] = (width + g.Tx - 1) / g.Tx; out[6] = rows; out[7] = g.nchunks;
     AswWaveGeom wg;
-    if (g.wave_rx && asw_wave_layout(wg, winSize, nD, g.wave_rx)) {      // a "tile" = the four strips of a workgroup's waves
+    if (g.wave_rx && asw_wave_layout(wg, winSize, nD, g.wave_rx, tune().wave_unroll != 0)) {      // a "tile" = the four strips of a workgroup's waves (LDS of the plain call: no cost dump)
         out[0] = wg.Txw * wg.waves; out[1] = wg.Dc; out[2] = 1; out[3] = 64 * wg.waves; out[4] = wg.wave_lds * wg.waves;
         out[5] = (width + out[0] - 1) / out[0]; out[7] = 1;
     }
