@@ -147,6 +147,17 @@ int ssamd_asw_alternate_multi(const uint8_t *img1, const uint8_t *img2, int heig
 int ssamd_remap_bgr_device(const uint8_t *d_src, int src_h, int src_w, const float *d_mapx, const float *d_mapy,
                            int dst_h, int dst_w, int interpolation, uint8_t *d_dst, void *stream);
 
+/* rectifyImages + StereoASW.compute in one call (the reference's own pipeline, examples/009 StereoMatchingASW.py:20-39:
+ * _rigs.py:543-567 feeding passive.py:88): the two RAW frames d_raw1 / d_raw2 (uint8 [src_height][src_width][3], device
+ * memory) are remapped through the rig's float32 maps [height][width] (device memory, 16-byte aligned) straight into the
+ * matcher's pixel records -- rectification and CIELab conversion are ONE launch and the rectified BGR frames never exist in
+ * HBM.  Bit-identical to ssamd_remap_bgr_device on each frame followed by ssamd_asw_device.  interpolation: 0 INTER_NEAREST,
+ * 1 INTER_LINEAR.  d_disparity int16 [height][width]. */
+int ssamd_asw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
+                               const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
+                               int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
+                               double gammaC, double gammaP, int consistent, int16_t *d_disparity, void *stream);
+
 /* RectifiedStereoRig.get3DPoints (reference _rigs.py:569-628 = cv2.reprojectImageTo3D):
  * d_points float32 [h][w][3] from int16 disparities and the 4x4 matrix Q (16 doubles, row
  * major, HOST memory).  h <= 65535; when w is a multiple of 4 (four pixels per thread) d_disparity must be 8-byte and

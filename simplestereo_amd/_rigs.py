@@ -409,6 +409,17 @@ class RectifiedStereoRig(StereoRig):
         return (_remap(img1, self.mapx1, self.mapy1, interpolation),
                 _remap(img2, self.mapx2, self.mapy2, interpolation))
 
+    def _device_maps(self, which, device):
+        """float32 maps of camera `which` (1 / 2) as tensors on `device`, uploaded once per rig, device and map array"""
+        import torch
+        mx, my = (self.mapx1, self.mapy1) if which == 1 else (self.mapx2, self.mapy2)
+        key = (which, str(device), mx.ctypes.data, mx.shape)
+        cache = self.__dict__.setdefault("_dev_maps", {})
+        if key not in cache:                      # maps change only through computeRectificationMaps
+            cache[key] = (torch.from_numpy(np.ascontiguousarray(mx)).to(device),
+                          torch.from_numpy(np.ascontiguousarray(my)).to(device))
+        return cache[key]
+
     def _remap_device(self, img, which, interpolation):
         import ctypes
         import torch
@@ -417,15 +428,9 @@ class RectifiedStereoRig(StereoRig):
             raise ValueError("device rectification expects uint8 [H,W,3] tensors")
         if interpolation not in (INTER_NEAREST, INTER_LINEAR):
             raise NotImplementedError("only INTER_NEAREST (0) and INTER_LINEAR (1) are available")
-        mx, my = (self.mapx1, self.mapy1) if which == 1 else (self.mapx2, self.mapy2)
-        key = (which, str(img.device), mx.ctypes.data, mx.shape)
-        cache = self.__dict__.setdefault("_dev_maps", {})
-        if key not in cache:                      # maps change only through computeRectificationMaps
-            cache[key] = (torch.from_numpy(np.ascontiguousarray(mx)).to(img.device),
-                          torch.from_numpy(np.ascontiguousarray(my)).to(img.device))
-        dmx, dmy = cache[key]
+        dmx, dmy = self._device_maps(which, img.device)
         src = img.contiguous()
-        h, w = mx.shape
+        h, w = (self.mapx1 if which == 1 else self.mapx2).shape
         out = torch.empty((h, w, 3), dtype=torch.uint8, device=img.device)
         with torch.cuda.device(img.device):
             stream = torch.cuda.current_stream(img.device).cuda_stream

@@ -35,13 +35,12 @@ __device__ __forceinline__ void asw_row_unpack6(AswRow6 &row, const uint2 packed
 }
 
 // KM: build rounds known at compile time (3 for the class default), 0: counted at run time
-// OCC: waves per SIMD the register allocation aims at.  3 (round 3): up to 168 VGPRs, all reads of a build in flight.  4 (round 4):
-// 128 VGPRs -- the 96 registers of accumulators and e window leave 32 for everything else, so the build takes its rounds one after
-// the other (12 instead of 36 registers in flight) and a few values of the row prologue live in scratch; pays when the wave's LDS
-// slice lets a fourth wave per SIMD be resident (AswWaveGeom::Se = 24).
 // CREG: window centres in registers (see asw_aggregate_wave_kernel): no cen array in LDS, two instead of three reads per weight pair.
-template <bool WITH_COSTS, int KM, int OCC = 3, bool CREG = false>
-__global__ __launch_bounds__(256, OCC) void asw_aggregate_wave6_kernel(const AswWaveArgs A)
+// (Round 4 also built a 128-VGPR form -- four waves per SIMD, build rounds one after the other -- and an e tile without its spare
+//  slot, Se = 24: the 96 registers of accumulators and e window leave too little, 6.49 vs 6.07 ms at 1080p / D 0..16 and 4.15 vs
+//  3.45 ms with register centres; Se = 24 bought a resident wave at win >= 31 and cost 10-16 % below.  profiles/r04_wave6_*.txt.)
+template <bool WITH_COSTS, int KM, bool CREG = false>
+__global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWaveArgs A)
 {
     static_assert(!CREG || KM > 0, "register centres need the straight-line build");
     constexpr int RX = 4, RD = 6, NWR = 10;          // nine right weights used, read as five pairs
@@ -148,17 +147,6 @@ __global__ __launch_bounds__(256, OCC) void asw_aggregate_wave6_kernel(const Asw
         }
         if constexpr (KM > 0) {
             const uint32_t ca = cen_b + lane16, da = dst_b + lane4, db_ = da + row1;
-            if constexpr (OCC >= 4) {
-#pragma unroll
-                for (int r = 0; r < KM; ++r) {
-                    const uint32_t ta = tap_b + tapoff[r];
-                    const float4 ce0 = ld4(ca + 1024 * r), ta0 = ld4(ta), tb0 = ld4(ta + 16);
-                    asm volatile("" ::"v"(ce0.w), "v"(ta0.w), "v"(tb0.w) : "memory");
-                    *(lds_f1)(da + 256 * r) = weight(ce0, ta0, pj0);
-                    *(lds_f1)(db_ + 256 * r) = weight(ce0, tb0, pj1);
-                }
-                return;
-            }
             float4 ce[KM], ta_[KM], tb[KM];
 #pragma unroll
             for (int r = 0; r < KM; ++r) {

@@ -8,6 +8,7 @@
 // output pixels read neighbouring source pixels) and writes 3 B per pixel; K6 reads 2 B and writes 12 B.
 #pragma once
 #include "common.hip.h"
+#include "lab_kernels.hip.h"
 
 namespace ssamd {
 
@@ -81,6 +82,35 @@ __global__ __launch_bounds__(256) void remap_bgr_kernel(const uint8_t *__restric
     for (long long p = 4 * nquad + tid; p < npix; p += stride) {
         const uint32_t v = remap_pixel(src, Hs, Ws, src_bytes, mapx[p], mapy[p], nearest);
         dst[3 * p] = (uint8_t)v; dst[3 * p + 1] = (uint8_t)(v >> 8); dst[3 * p + 2] = (uint8_t)(v >> 16);
+    }
+}
+
+// K5+K0 (round 4): rectification remap and Lab records of BOTH images in one launch -- RectifiedStereoRig.rectifyImages
+// (reference _rigs.py:543-567) feeding StereoASW.compute (passive.py:88), the reference's own pipeline (examples/009:20-39),
+// without the rectified BGR frames ever existing in HBM: the remapped pixel goes straight into bgr_to_lab and the
+// 16-byte record.  Same arithmetic as remap_bgr_kernel + bgr2lab_records_pair_kernel, so the records (and the maps
+// matched from them) are bit-identical to the two-step path.  Rows [row_lo, row_hi) of the destination only (a matcher
+// call touches its output rows +- winSize / 2).
+struct RemapSrc {
+    const uint8_t *src1, *src2;      // raw frames [Hs][Ws][3]
+    const float *mapx1, *mapy1, *mapx2, *mapy2;      // [H][W] float32 maps of the rig
+    int Hs, Ws, nearest;
+};
+__global__ __launch_bounds__(256) void remap_lab_records_pair_kernel(const RemapSrc S, PixRec *__restrict__ recL, PixRec *__restrict__ recR,
+                                                                     long long pix0, long long npix)
+{
+    const size_t src_bytes = (size_t)S.Hs * S.Ws * 3;
+    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; q < 2 * npix; q += stride) {
+        const bool right = q >= npix;
+        const long long p = pix0 + (right ? q - npix : q);
+        const uint32_t v = remap_pixel(right ? S.src2 : S.src1, S.Hs, S.Ws, src_bytes, (right ? S.mapx2 : S.mapx1)[p],
+                                       (right ? S.mapy2 : S.mapy1)[p], S.nearest);
+        PixRec o;
+        bgr_to_lab(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, o.L, o.a, o.b);
+        o.bgrx = v;
+        (right ? recR : recL)[p] = o;
     }
 }
 

@@ -70,7 +70,6 @@ struct Tuning {
     int autotune_env = -2;            // -2 unset
     int evol_fail = 0;                // test hook: 1 = the TAD volume's allocation really fails (a hipMalloc no device can serve)
     int wave_creg = 1;                // 0: the wave kernel keeps its window centres in LDS (round-3 form)
-    int wave6_occ = 0, wave6_se = 0;  // 0: the host decides; 3 / 4: waves per SIMD the six-per-lane wave kernel is compiled for; 24 / 40: bytes per e column
     int asw_tail = -1;                // -1: the host decides; 0: never split the last partial round of workgroups into half-width tiles; 1: whenever possible
 };
 std::mutex g_tune_mutex;
@@ -100,8 +99,6 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_EVOL_FAIL") t.evol_fail = num(0);
     else if (name == "SSAMD_ASW_TAIL") t.asw_tail = num(-1);
     else if (name == "SSAMD_ASW_WAVE_CREG") t.wave_creg = num(1);
-    else if (name == "SSAMD_ASW_WAVE6_OCC") t.wave6_occ = num(0);
-    else if (name == "SSAMD_ASW_WAVE6_SE") t.wave6_se = num(0);
     else return false;
     return true;
 }
@@ -109,7 +106,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
-                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE6_OCC", "SSAMD_ASW_WAVE6_SE", "SSAMD_ASW_WAVE_CREG"};
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -526,7 +523,6 @@ bool asw_wave_layout_one(AswWaveGeom &g, int win, int DG, int rx, int nxg, bool 
     // group stride rx * Se) spread over the LDS banks -- with Se = 32 the 12 column groups of D 0..16 all hit the same
     // five banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21)
     g.Se = rd == 6 ? 8 * ((g.DG + 1) | 1) : 4 * (g.DG | 1);        // (six per lane: 8-byte slots, an odd number of them and one to spare)
-    if (rd == 6 && tune().wave6_se == 24) g.Se = 8 * g.DG;          // round 4: no spare slot (a smaller LDS slice per wave: more resident waves)
     g.waves = tune().wave_wg ? tune().wave_wg : 1;
     // order matters: the build's last round reads up to 127 entries past the end of the centres and of each pixel
     // row (asw_wave_kernel.hip.h) -- into the array that follows, never past the e tile -- and the merged build
@@ -652,7 +648,7 @@ bool asw_geometry_forced()
     const Tuning &t = tune();
     return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
            t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0 || t.wave_rd != 0 ||
-           t.wave6_occ != 0 || t.wave6_se != 0 || t.wave_creg != 1;
+           t.wave_creg != 1;
 }
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
@@ -868,9 +864,11 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
     return SSAMD_OK;
 }
 
+// rm != nullptr: dL / dR are unused; the pixel records come from the RAW frames through the rig's maps
+// (remap_lab_records_pair_kernel: rectification + Lab in one launch)
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
-                    float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr)
+                    float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr, const RemapSrc *rm = nullptr)
 {
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
@@ -955,8 +953,12 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             const long long np2 = (long long)(r1 - r0) * W;
             const int blocks = (int)std::min<long long>((2 * np2 + 255) / 256, 256 * 8);
             Timed t(c, s, SSAMD_K_LAB);
-            hipLaunchKernelGGL(bgr2lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3, dR + (size_t)r0 * W * 3,
-                               (PixRec *)c.recL.ptr + (size_t)r0 * W, (PixRec *)c.recR.ptr + (size_t)r0 * W, np2);
+            if (rm)
+                hipLaunchKernelGGL(remap_lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, *rm, (PixRec *)c.recL.ptr, (PixRec *)c.recR.ptr,
+                                   (long long)r0 * W, np2);
+            else
+                hipLaunchKernelGGL(bgr2lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3, dR + (size_t)r0 * W * 3,
+                                   (PixRec *)c.recL.ptr + (size_t)r0 * W, (PixRec *)c.recR.ptr + (size_t)r0 * W, np2);
             HIP_TRY(hipGetLastError());
         }
 
@@ -1045,11 +1047,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 const bool unrolled = tune().wave_unroll != 0;
                 if (wa.g.RD == 6) {                                                         // six disparities per lane
                     wk = d_costs ? asw_aggregate_wave6_kernel<true, 0> : asw_aggregate_wave6_kernel<false, 0>;
-                    const bool occ4 = tune().wave6_occ == 4;
-                    if (unrolled && !d_costs && wa.g.K == 3)
-                        wk = wa.g.creg ? asw_aggregate_wave6_kernel<false, 3, 3, true> : occ4 ? asw_aggregate_wave6_kernel<false, 3, 4> : asw_aggregate_wave6_kernel<false, 3>;
-                    else if (unrolled && !d_costs && wa.g.K == 2)
-                        wk = wa.g.creg ? asw_aggregate_wave6_kernel<false, 2, 3, true> : occ4 ? asw_aggregate_wave6_kernel<false, 2, 4> : asw_aggregate_wave6_kernel<false, 2>;
+                    if (unrolled && !d_costs && wa.g.K == 3) wk = wa.g.creg ? asw_aggregate_wave6_kernel<false, 3, true> : asw_aggregate_wave6_kernel<false, 3>;
+                    else if (unrolled && !d_costs && wa.g.K == 2) wk = wa.g.creg ? asw_aggregate_wave6_kernel<false, 2, true> : asw_aggregate_wave6_kernel<false, 2>;
                 } else if (unrolled && !d_costs && wa.g.merged) {
                     const int key = wa.g.RX * 10 + wa.g.K;                                  // merged build, K rounds
                     if (key == 42) wk = wa.g.creg ? asw_aggregate_wave_kernel<false, 4, 0, 0, 2, true> : asw_aggregate_wave_kernel<false, 4, 0, 0, 2>;   // class default D 0..16 four per lane: 48 + 67 centres
@@ -1679,6 +1678,24 @@ int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream);
+}
+
+int ssamd_asw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
+                               const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
+                               int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
+                               double gammaC, double gammaP, int consistent, int16_t *d_disparity, void *stream)
+{
+    if (!d_raw1 || !d_raw2 || !d_mapx1 || !d_mapy1 || !d_mapx2 || !d_mapy2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (src_height <= 0 || src_width <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (interpolation != 0 && interpolation != 1) return fail(SSAMD_EINVAL, "only INTER_NEAREST (0) and INTER_LINEAR (1) are supported");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    RemapSrc rm;
+    rm.src1 = d_raw1; rm.src2 = d_raw2; rm.mapx1 = d_mapx1; rm.mapy1 = d_mapy1; rm.mapx2 = d_mapx2; rm.mapy2 = d_mapy2;
+    rm.Hs = src_height; rm.Ws = src_width; rm.nearest = interpolation == 0 ? 1 : 0;
+    return asw_device_impl(*c, nullptr, nullptr, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                           d_disparity, nullptr, (hipStream_t)stream, false, nullptr, &rm);
 }
 
 int ssamd_asw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,

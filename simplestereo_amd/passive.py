@@ -195,7 +195,7 @@ class StereoASW():
     def _alternate(self, cons):
         return bool(getattr(self, "alternate", False))
 
-    def compute(self, img1, img2, devices=None):
+    def compute(self, img1, img2, devices=None, rectify=None, interpolation=1):
         """
         Disparity map of a rectified BGR pair.
 
@@ -203,7 +203,16 @@ class StereoASW():
         order (or two device tensors, see the module docstring).  Returns a new ``numpy.int16``
         array ``[H, W]`` of left-referenced disparities.  ``devices`` (extension, host arrays only):
         list of GPU indices that share the frame as row strips.
+
+        ``rectify`` (extension, device tensors only): a ``RectifiedStereoRig`` whose maps are computed -- ``img1`` / ``img2``
+        are then the RAW frames, and ``rig.rectifyImages(img1, img2, interpolation)`` followed by ``compute`` (the reference's
+        pipeline, examples/009) runs as one call in which rectification and Lab conversion are a single launch and the
+        rectified frames never exist in HBM.  Same map, bit for bit, as the two calls.
         """
+        if rectify is not None:
+            if not (_is_device_tensor(img1) and _is_device_tensor(img2)) or devices is not None:
+                raise ValueError("rectify=rig applies to two device tensors (raw frames resident in HBM)")
+            return self._compute_rectified_device(rectify, img1, img2, interpolation)
         if _is_device_tensor(img1) and _is_device_tensor(img2):
             if devices is not None:
                 raise ValueError("devices=[...] applies to host arrays; device tensors are matched where they live")
@@ -232,6 +241,37 @@ class StereoASW():
                                         out.ctypes.data, dev))
         except _native.NativeError as e:
             _raise_native(e)
+        return out
+
+    def _compute_rectified_device(self, rig, raw1, raw2, interpolation=1):
+        """raw frames -> (rectification + Lab records in one launch) -> matcher: ssamd_asw_rectified_device"""
+        import torch
+        lib = _native.lib()
+        win, maxd, mind, gc, gp, cons = self._params()
+        if self._alternate(cons):
+            raise ValueError("rectify=rig is not available with alternate=True")
+        a, b = _check_pair_tensors(raw1, raw2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        if interpolation not in (0, 1):
+            raise NotImplementedError("only INTER_NEAREST (0) and INTER_LINEAR (1) are available")
+        if getattr(rig, "mapx1", None) is None:
+            raise ValueError("the rig has no rectification maps: call computeRectificationMaps() first")
+        mx1, my1 = rig._device_maps(1, a.device)
+        mx2, my2 = rig._device_maps(2, a.device)
+        if mx1.shape != mx2.shape:
+            raise ValueError("Wrong image dimensions!")
+        H, W = int(mx1.shape[0]), int(mx1.shape[1])
+        out = torch.empty((H, W), dtype=torch.int16, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            try:
+                _native.check(lib.ssamd_asw_rectified_device(a.data_ptr(), b.data_ptr(), int(a.shape[0]), int(a.shape[1]),
+                                                             mx1.data_ptr(), my1.data_ptr(), mx2.data_ptr(), my2.data_ptr(), H, W,
+                                                             int(interpolation), win, maxd, mind, gc, gp, cons, out.data_ptr(),
+                                                             ctypes.c_void_p(stream)))
+            except _native.NativeError as e:
+                _raise_native(e)
         return out
 
     def _compute_device(self, t1, t2, out_row0=0, out_rows=None, row_parity=0):

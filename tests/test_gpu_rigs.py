@@ -141,3 +141,28 @@ def test_device_chain_rectify_match_reproject(env):
     hd = m.compute(hL, hR)
     assert np.array_equal(disp.cpu().numpy(), hd)
     assert np.allclose(pts.cpu().numpy(), rig.get3DPoints(hd), rtol=2e-6, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("dest,params,interp", [((320, 180), dict(winSize=35, maxDisparity=25, minDisparity=4, gammaC=15, consistent=True), 1),
+                                                ((640, 360), dict(winSize=35, maxDisparity=100, minDisparity=4, gammaC=15), 1),
+                                                ((161, 91), dict(winSize=11, maxDisparity=30), 0)])
+def test_rectify_and_match_in_one_call(dest, params, interp, env):
+    """compute(raw1, raw2, rectify=rig): rectification + Lab records as ONE launch (remap_lab_records_pair_kernel), the rectified
+    frames never in HBM -- the same map, bit for bit, as rectifyImages followed by compute (the reference's pipeline of
+    examples/009: quarter-size destination with the example's parameters; a destination large enough for the phase-shifted
+    kernel; odd sizes with nearest-neighbour maps)"""
+    ss, torch, rig = env
+    rig.computeRectificationMaps(destDims=dest)
+    w, h = rig.res1
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(h, w, 120, 5)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(**params)
+    two_step = m.compute(*rig.rectifyImages(tL, tR, interpolation=interp))
+    fused = m.compute(tL, tR, rectify=rig, interpolation=interp)
+    assert fused.is_cuda and fused.dtype == torch.int16 and tuple(fused.shape) == (dest[1], dest[0])
+    assert torch.equal(fused, two_step)
+    with pytest.raises(ValueError):
+        m.compute(L, R, rectify=rig)                      # host arrays: the two-step path is the one to use
+    with pytest.raises(ValueError):
+        ss.passive.StereoASW(alternate=True, **params).compute(tL, tR, rectify=rig)

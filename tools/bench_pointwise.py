@@ -46,7 +46,11 @@ def measure(sizes=((1080, 1920), (2160, 4096))):
 
         def lab():
             m.compute(img, img)
+        def fused():          # rectification + Lab records of both images in ONE launch (ssamd_asw_rectified_device): 8 B maps + 3 B source in, 16 B out
+            _native.check(lib.ssamd_asw_rectified_device(img.data_ptr(), img.data_ptr(), H, W, dmx.data_ptr(), dmy.data_ptr(), dmx.data_ptr(),
+                                                         dmy.data_ptr(), H, W, 1, 5, 3, 0, 5.0, 17.5, 0, disp.data_ptr(), stream))
         for name, fn, slot, bpp, launches_per_call in (("K5 remap_bgr_kernel", remap, _native.K_REMAP, 8 + 3 + 3, 1),
+                                                       ("K5+K0 remap_lab_records_pair_kernel (both images)", fused, _native.K_LAB, 2 * (8 + 3 + 16), 1),
                                                        ("K6 reproject_kernel", reproject, _native.K_REPROJECT, 2 + 12, 1),
                                                        ("K0 bgr2lab_records_pair_kernel (both images)", lab, _native.K_LAB, 2 * (3 + 16), 1)):
             for _ in range(3):
@@ -60,7 +64,7 @@ def measure(sizes=((1080, 1920), (2160, 4096))):
             ms, launches = _native.profile_read()
             lib.ssamd_profile_enable(0)
             per = ms[slot] / max(1, launches[slot])          # ms per launch
-            if name.startswith("K0"):
+            if name.startswith("K0") or name.startswith("K5+K0"):
                 assert launches[slot] == 20, launches[slot]      # one launch converts both images (round 3)
             gbs = bpp * H * W / (per * 1e-3) / 1e9
             res["%s %dx%d" % (name, W, H)] = {"ms": round(per, 4), "algorithmic_bytes_per_pixel": bpp, "GB/s": round(gbs, 1),
