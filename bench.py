@@ -559,13 +559,23 @@ def main():
         args.gpus = world                  # the launcher's world size is authoritative
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # TEST HOOK (tests/test_gpu_rccl_world1.py, never a measurement): SSAMD_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    # moves the messages over gloo through host staging -- RCCL refuses two ranks on one device -- so that the N > 1
+    # branches of this file (per-rank roofline, map equality with one GPU, accuracy through the strips) can be executed
+    # on a box with ONE GPU.  The line says so (`rccl.backend` = "gloo", `shared_gpu_test_mode`).
+    share_gpu = os.environ.get("SSAMD_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SSAMD_BENCH_FORCE_DIST") == "1"   # FORCE: exercise the RCCL path at N=1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import simplestereo_amd as ss
     from simplestereo_amd import _native, strips
@@ -619,7 +629,7 @@ def main():
     lib.ssamd_profile_enable(0)
     rccl = None
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # what every rank actually ran on, collected on rank 0
@@ -638,6 +648,8 @@ def main():
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "flat_all_gather_into_tensor": bool(strip_ctx.flat_gather),
                 "halo_rows_per_side": strip_ctx.pad, "halo_message_bytes": strip_ctx.pad * W * 3,
                 "gather_bytes_per_rank": strip_ctx.rows_max * W * 2, "p2p_loopback_probe": p2p_loopback, "ranks": per_rank}
+        if share_gpu:
+            rccl["shared_gpu_test_mode"] = "every rank on GPU 0, messages over gloo through host staging: NOT a scaling measurement"
         try:
             rccl["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:      # noqa: BLE001

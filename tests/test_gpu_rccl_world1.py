@@ -99,6 +99,33 @@ def test_bench_forced_distributed_line_at_world_1():
     assert "rccl" not in plain
 
 
+def test_bench_line_of_a_two_rank_run_explains_itself():
+    """the N > 1 branches of bench.py -- slowest rank's roofline, per-rank kernel ms, the gathered map against ONE launch over
+    the whole frame, the accuracy figure computed THROUGH the strips -- executed with two ranks sharing GPU 0 over gloo
+    (SSAMD_BENCH_SHARE_GPU: RCCL refuses two ranks on one device); launched the way the driver launches a scaling run"""
+    env = dict(os.environ, SSAMD_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SSAMD_BENCH_FORCE_DIST", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--config", "c2_480p_d64_w35"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    rc = line["rccl"]
+    assert rc["world_size"] == 2 and len(rc["ranks"]) == 2 and "shared_gpu_test_mode" in rc
+    assert [r_["strip_rows"] for r_ in rc["ranks"]] == [[0, 240], [240, 480]]
+    assert all(r_["kernel_ms"] > 0 and r_["taps"] > 0 and 0 < r_["valu_frac"] < 1 for r_ in rc["ranks"])
+    assert rc["kernel_ms_min"] <= rc["kernel_ms_max"]
+    assert line["roofline"]["of_rank"] in (0, 1) and line["roofline"]["kernel_ms"] == rc["kernel_ms_max"]
+    assert line["config"]["checksum_equals_single_gpu"] is True and line["config"]["checksum_single_gpu"] == line["config"]["checksum"]
+    b = line["bad1_vs_cpu_ref"]
+    assert "StripContext over 2 ranks" in b["through"] and b["percent"] <= 0.5 and set(b["cases"]) == {"W3a", "W3b", "P2a"}
+    assert b["cases"]["P2a"]["exact_percent"] >= 99.0
+
+
 def test_bench_line_carries_the_contract_keys():
     """the line the driver parses: metric / value / unit / steps, `roofline` {bound, achieved, peak, unit, frac, traffic},
     `cpu_baseline` {value, unit, cores, kind, sample}, the accuracy figure on the reference's strips -- on a small
