@@ -59,6 +59,7 @@ struct AswGeom {
                                  //    instead (small disparity ranges); the other fields then describe the fallback geometry
     int off_wL, off_wR, off_e, off_labL, off_labR, off_bgrL, off_bgrR, off_bestL, off_bestR, off_cen, off_prox;
     int lds_bytes;
+    int lds_bytes_evol;          // phase-shifted kernel with the pre-computed TAD volume: LDS without the staged colour bytes (bgrL / bgrR are last)
 };
 
 struct AswArgs {

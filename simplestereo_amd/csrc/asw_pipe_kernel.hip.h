@@ -201,7 +201,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
             v.bgrx = 0u;
             if ((unsigned)col < (unsigned)W) v = (isL ? rowL : rowR)[col];
             (isL ? labL + buf * nL : labR + buf * nR)[idx] = make_float4(v.L, v.a, v.b, 0.f);
-            (isL ? bgrL + buf * nL : bgrR + buf * nR)[idx] = v.bgrx;
+            if (!A.evol) (isL ? bgrL + buf * nL : bgrR + buf * nR)[idx] = v.bgrx;      // (only the in-kernel e tiles read them; not allocated otherwise)
         }
     };
     // tasks [t_lo, t_hi) of the e tile of window row i (task = tap column ul x pair of disparity groups, flat index

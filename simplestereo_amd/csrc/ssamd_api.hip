@@ -414,12 +414,21 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
     g.off_e = take((size_t)g.e_bytes * (g.e2 ? 2 : 1));
     g.off_labL = take((size_t)g.nL * 16 * 2);    // staging is double-buffered (prefetch of the next row)
     g.off_labR = take((size_t)g.nR * 16 * 2);
-    g.off_bgrL = take((size_t)g.nL * 4 * 2);
-    g.off_bgrR = take((size_t)g.nR * 4 * 2);
+    if (!g.pipe) {
+        g.off_bgrL = take((size_t)g.nL * 4 * 2);
+        g.off_bgrR = take((size_t)g.nR * 4 * 2);
+    }
     g.off_bestL = take((size_t)g.Tx * 8);
     g.off_bestR = take((size_t)(g.nRc + 1) * 8);
     g.off_cen = take((size_t)(g.Tx + g.nRc) * 16);
     g.off_prox = take((size_t)win * 4 * 2);      // one window row of proximity weights, double-buffered
+    g.lds_bytes_evol = (int)off;
+    if (g.pipe) {
+        // the staged colour bytes only feed the in-kernel e tiles: LAST in the layout, so that a launch that has the pre-computed
+        // TAD volume asks for lds_bytes_evol and leaves them out (round 4: LDS is what bounds the resident workgroups of mid-size tiles)
+        g.off_bgrL = take((size_t)g.nL * 4 * 2);
+        g.off_bgrR = take((size_t)g.nR * 4 * 2);
+    }
     g.lds_bytes = (int)off;
     return off <= limit;
 }
@@ -719,7 +728,8 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
             }
             g.nchunks = nch;
             const int waves = g.threads / 64, per_simd = (waves + 3) / 4;
-            const int k = std::min(max_wps / per_simd, (160 * 1024) / g.lds_bytes);
+            // (the phase-shifted kernel normally runs with the TAD volume and then leaves the staged colour bytes out of its LDS)
+            const int k = std::min(max_wps / per_simd, (160 * 1024) / (piped && tune().asw_evol != 0 ? g.lds_bytes_evol : g.lds_bytes));
             if (k < 1) continue;
             // per-thread aggregation cycles of one window row; the 4-column tile spends the same address and
             // e-row work on half the taps; the phase-shifted kernel's step is 107 instead of 111 instructions
@@ -1082,7 +1092,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                     else if (g.SL == 88 && g.SR == 348 && g.Se == 272) pk = asw_aggregate_pipe_kernel<false, 88, 348, 272>;
                     else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = asw_aggregate_pipe_kernel<false, 216, 284, 80>;
                 }
-                if (int grc = grant_dyn_lds(c, (const void *)pk, g.lds_bytes)) return grc;
+                const int pipe_lds = a.evol ? g.lds_bytes_evol : g.lds_bytes;          // (no staged colour bytes when the e tiles come from the volume)
+                if (int grc = grant_dyn_lds(c, (const void *)pk, pipe_lds)) return grc;
                 // The last PARTIAL round of workgroups (round 4).  The kernel keeps one 12-wave workgroup per CU, so a launch
                 // of n workgroups takes ceil(n / 256) rounds: a row strip of an 8-GPU run (135 rows x 16 tiles = 8.44 rounds)
                 // pays nine.  When the last round is at most half full, the rows that fill whole rounds keep the tile and the
@@ -1105,7 +1116,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                         }
                     }
                 }
-                hipLaunchKernelGGL(pk, dim3(grid.x, rows_main, grid.z), block, g.lds_bytes, s, a);
+                hipLaunchKernelGGL(pk, dim3(grid.x, rows_main, grid.z), block, pipe_lds, s, a);
                 HIP_TRY(hipGetLastError());
                 if (rows_main < grows) {
                     ++c.tail_splits;
@@ -1118,9 +1129,10 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                     if (t.keyR) t.keyR += skip;
                     if (t.costs) t.costs += skip * (size_t)nD;
                     auto tk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
-                    if (int grc = grant_dyn_lds(c, (const void *)tk, tail_g.lds_bytes)) return grc;
+                    const int tail_lds = a.evol ? tail_g.lds_bytes_evol : tail_g.lds_bytes;
+                    if (int grc = grant_dyn_lds(c, (const void *)tk, tail_lds)) return grc;
                     hipLaunchKernelGGL(tk, dim3((W + tail_g.Tx - 1) / tail_g.Tx, grows - rows_main, tail_g.nchunks), dim3(tail_g.threads),
-                                       tail_g.lds_bytes, s, t);
+                                       tail_lds, s, t);
                     HIP_TRY(hipGetLastError());
                 }
                 return SSAMD_OK;

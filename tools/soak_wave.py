@@ -20,7 +20,7 @@ rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
 lib = _native.lib()
 t_end = time.time() + budget
 n = skipped = 0
-HOOKS = ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL", "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_WAVE_RD")
+HOOKS = ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL", "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_WAVE_CREG")
 while time.time() < t_end:
     H, W = int(rng.integers(1, 140)), int(rng.integers(1, 700))
     if rng.random() < 0.1:
@@ -54,6 +54,7 @@ while time.time() < t_end:
         _native.set_option("SSAMD_ASW_WAVE_UNROLL", unroll_)
         _native.set_option("SSAMD_ASW_WAVE_MERGE", None if rng.random() < 0.7 else "0")      # round 3: merged build rounds (default) / separate
         _native.set_option("SSAMD_ASW_WAVE_RD", None if rng.random() < 0.7 else "4")         # six disparities per lane where the host takes them / never
+        _native.set_option("SSAMD_ASW_WAVE_CREG", None if rng.random() < 0.75 else "0")       # round 4: window centres in registers (default) / in LDS
         if _native.asw_kernel_form(W, H, win, maxd, mind)["wave_kernel"] != int(rx):
             skipped += 1
             continue
