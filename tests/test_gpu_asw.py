@@ -526,3 +526,33 @@ def test_asw_wave_kernel_six_disparities_per_lane(win, maxd, mind, consistent, s
     finally:
         for k in ("SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_RD"):
             _native.set_option(k, None)
+
+
+@pytest.mark.parametrize("shape,win,maxd,mind,consistent", [((48, 160), 65, 20, 0, False), ((60, 140), 99, 12, 2, True),
+                                                             ((50, 180), 127, 40, 0, False), ((40, 120), 255, 9, 0, True),
+                                                             ((30, 200), 191, 70, 0, False)])
+def test_asw_windows_beyond_63(shape, win, maxd, mind, consistent, ss):
+    """windows of 65 .. 255 columns (the geometry search accepts up to 255; the small-range wave kernel stops at 63, so these run
+    the workgroup kernels with tap-column chunking): raw costs within the stated tolerance of the fp64 oracle, maps within the bars,
+    GSW with the same windows bit-exact"""
+    from oracle import oracle
+    from simplestereo_amd.synth import make_pair
+    H, W = shape
+    L, R, _ = make_pair(H, W, maxd, 31 + win)
+    p = dict(winSize=win, maxDisparity=maxd, minDisparity=mind, gammaC=7.0, gammaP=40.0)
+    d = ss.passive.StereoASW(consistent=consistent, **p).compute(L, R)
+    ref, cref = oracle.asw(L, R, consistent=False, return_costs=True, **p)
+    if consistent:
+        ref = oracle.asw(L, R, consistent=True, **p)
+    nD = maxd - mind + 1
+    c = np.empty((H, W, nD), np.float32)
+    _native.check(_native.lib().ssamd_asw_costs(L.ctypes.data, R.ctypes.data, H, W, win, maxd, mind, 7.0, 40.0, c.ctypes.data, -1))
+    assert np.array_equal(np.isnan(c), np.isnan(cref))
+    ok = ~np.isnan(cref)
+    assert (np.abs(c[ok] - cref[ok]) / np.maximum(1.0, np.abs(cref[ok]))).max() <= 1e-4
+    diff = np.abs(d.astype(np.int32) - ref.astype(np.int32))
+    print("win %d: exact %.4f within-1 %.4f" % (win, np.mean(diff == 0), np.mean(diff <= 1)))
+    assert np.mean(diff <= 1) >= 0.995 and np.mean(diff == 0) >= 0.99
+    if win <= 127:          # (the closed-form oracle needs seconds for these; the literal relaxation would need hours)
+        g = dict(winSize=win, maxDisparity=maxd, minDisparity=mind, gamma=10, fMax=120, iterations=3)
+        assert np.array_equal(ss.passive.StereoGSW(**g).compute(L, R), oracle.gsw(L, R, closed=True, **g))
