@@ -51,6 +51,13 @@ def quarter(img):
     return np.ascontiguousarray(((q + 2) >> 2).astype(np.uint8))
 
 
+def half(img):
+    """cv2.resize(img, None, fx=0.5, fy=0.5) with INTER_LINEAR: the mean of every 2 x 2 block, rounded half up"""
+    H, W = img.shape[0] // 2 * 2, img.shape[1] // 2 * 2
+    s = img[:H, :W].astype(np.uint32)
+    return np.ascontiguousarray(((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+
+
 def inputs():
     import simplestereo_amd as ss
     rig = ss.RectifiedStereoRig.fromFile(os.path.join(RES, "2", "rigRect.json"))
@@ -62,6 +69,7 @@ def inputs():
         "lawn_brick_L": c(l[130:194]), "lawn_brick_R": c(r[130:194]),              # 64 x 1280: chair, brick wall, bicycle
         "lawn_grass_L": c(l[600:664]), "lawn_grass_R": c(r[600:664]),              # 64 x 1280: grass + the black margin below
         "new3_L": c(n3l[300:348]), "new3_R": c(n3r[300:348]),                      # 48 x 1280: unrectified capture
+        "lawn_half_L": half(l), "lawn_half_R": half(r),                            # 360 x 640: the WHOLE rectified frame at half size
     }
 
 
@@ -79,6 +87,10 @@ CASES = {
     # the class default StereoASW() / StereoGSW() on the quarter-size pair
     "P4a": ("lawn_quarter", A(winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False)),
     "P4b": ("lawn_quarter", G(winSize=11, maxDisparity=16, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20)),
+    # the WHOLE frame -- sky, brick, chair, bicycle, mower, lawn and the black margins of the rectification -- at half size with
+    # the example's window and twice its range, left-right check on; and GSW on the same frame
+    "P5a": ("lawn_half", A(winSize=35, maxDisparity=50, minDisparity=8, gammaC=15, gammaP=17.5, consistent=True)),
+    "P5b": ("lawn_half", G(winSize=11, maxDisparity=50, minDisparity=8, gamma=10, fMax=120, iterations=3, bins=20)),
 }
 
 

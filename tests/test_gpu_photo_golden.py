@@ -4,8 +4,9 @@ tests/golden/photo_cases.npz holds the reference extension's (oracle/_ref, _pass
 its own ASW example (examples/009 StereoMatchingASW.py:20-39: examples/res/2/lawn_{L,R}.png, rectified with the shipped rig): the
 quarter-size pair with the example's verbatim parameters (win 35, D 4..25, gammaC 15; plain, consistent, and the class defaults of
 StereoASW() / StereoGSW()), two full-width 1280 x 64 strips of the native-size pair with D 4..100 (brick / chair / bicycle; grass +
-the black margin rectification leaves), and a 1280 x 48 strip of an unrectified capture from examples/res/new (ASW consistent and
-GSW); inputs in photo_pairs.npz, generator tests/golden/make_golden_photo.py.  Smooth natural content -- lawn, defocus, the
+the black margin rectification leaves), a 1280 x 48 strip of an unrectified capture from examples/res/new (ASW consistent and
+GSW), and the WHOLE rectified frame at half size (640 x 360: sky, brick, chair, bicycle, mower, lawn, black margins; ASW win 35
+D 8..50 consistent, GSW); inputs in photo_pairs.npz, generator tests/golden/make_golden_photo.py.  Smooth natural content -- lawn, defocus, the
 constant margins -- is what the Tsukuba crops and the synthetic frames of the other goldens do not contain.
 
 Bars, WITHOUT any tie exclusion: ASW (fp32 kernels vs the fp64 reference) >= 99.5 % of all pixels within 1 level (north_star) and
@@ -49,7 +50,7 @@ def tie_audit(a, b, p, d, ref):
     return np.array(out)
 
 
-@pytest.mark.parametrize("cid", ["P1", "P1c", "P2a", "P2b", "P3a", "P4a"])
+@pytest.mark.parametrize("cid", ["P1", "P1c", "P2a", "P2b", "P3a", "P4a", "P5a"])
 def test_asw_photographs_vs_reference(cid, photo):
     import simplestereo_amd as ss
     maps, meta, pairs = photo
@@ -76,7 +77,7 @@ def test_asw_photographs_vs_reference(cid, photo):
     assert np.array_equal(ss.passive.StereoASW(**p).compute(ta, tb).cpu().numpy(), d)
 
 
-@pytest.mark.parametrize("cid", ["P3b", "P4b"])
+@pytest.mark.parametrize("cid", ["P3b", "P4b", "P5b"])
 def test_gsw_photographs_vs_reference_bit_exact(cid, photo):
     import simplestereo_amd as ss
     maps, meta, pairs = photo

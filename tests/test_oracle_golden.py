@@ -161,7 +161,7 @@ def test_reference_module_agrees_when_present(golden_cases, golden_inputs):
     assert np.array_equal(d, maps["G5c"])
 
 
-@pytest.mark.parametrize("cid", ["P1", "P1c", "P2a", "P3b", "P4a", "P4b"])
+@pytest.mark.parametrize("cid", ["P1", "P1c", "P2a", "P3b", "P4a", "P4b", "P5b"])
 def test_oracle_on_photographs(cid):
     """the C restatement (hoisted / closed-form modes) against the reference's maps of REAL PHOTOGRAPHS -- the lawn pair of the
     reference's own ASW example (examples/009) at quarter size with the example's parameters and as a full-width native strip
