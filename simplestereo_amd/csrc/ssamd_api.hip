@@ -1278,20 +1278,55 @@ bool gsw_layout(GswGeom &g, int win, int XG, int DG, int Ty, size_t limit, int H
 // (output row, window row) pair pays its weights (c_w per element) and its taps (c_tap per cell).
 int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD);
 
+std::map<std::array<int, 4>, GswGeom> g_gsw_geom_cache;
+std::map<std::array<int, 4>, bool> g_gsw_geom_tuned;      // shapes whose cached geometry was picked by measurement (gsw_device_impl)
+
 int gsw_choose_geometry(GswGeom &best, int W, int rows, int win, int nD)      // cached like asw_choose_geometry
 {
-    static std::map<std::array<int, 4>, GswGeom> cache;
     if (!tune().gsw_geom.empty()) return gsw_search_geometry(best, W, rows, win, nD);
     std::lock_guard<std::mutex> glk(g_geom_mutex);
     const std::array<int, 4> key{W, rows, win, nD};
-    auto it = cache.find(key);
-    if (it != cache.end()) { best = it->second; return SSAMD_OK; }
+    auto it = g_gsw_geom_cache.find(key);
+    if (it != g_gsw_geom_cache.end()) { best = it->second; return SSAMD_OK; }
     const int rc = gsw_search_geometry(best, W, rows, win, nD);
     if (rc == SSAMD_OK) {
-        if (cache.size() > 256) cache.clear();
-        cache[key] = best;
+        if (g_gsw_geom_cache.size() > 256) { g_gsw_geom_cache.clear(); g_gsw_geom_tuned.clear(); }
+        g_gsw_geom_cache[key] = best;
     }
     return rc;
+}
+
+// Autotuning candidates (round 4).  The cost model above is calibrated on config 4 (193 disparities) and is up to 38 % off for
+// small ranges -- the class default of StereoGSW is maxDisparity = 16 -- where narrow tiles with ONE wave per thread group and
+// four-row strips win (1080p / win 11: D 0..16 2.09 -> 1.40 ms with "10,5,2,2", D 0..7 1.91 -> 1.18 ms with "16,2,2,2", D 0..32
+// 2.55 -> 1.97 ms with "14,9,2,2"; profiles/r04_gsw_geometry_small_ranges.txt).  Candidates: the model's choice first, then for
+// strips of 2 / 4 / 8 rows the tiles whose thread groups fill whole waves (XG x DG just below 64, 128, ... 512 lanes).
+void gsw_candidates(std::vector<GswGeom> &out, const GswGeom &model, int W, int rows, int win, int nD)
+{
+    out.clear();
+    out.push_back(model);
+    const int Ty = 2, Rd = 4;
+    if (rows < 2) return;
+    for (int nch = model.nchunks; nch <= model.nchunks + 1 && nch <= nD; ++nch) {
+        const int per = (nD + nch - 1) / nch, DG = round_up(per, Rd) / Rd;
+        if (DG > 64 || (nD + DG * Rd - 1) / (DG * Rd) != nch) continue;
+        for (int Hy : {1, 2, 4}) {
+            if (Ty * Hy > std::max(rows, 2)) break;
+            for (int T : {32, 64, 128, 192, 256, 384, 512}) {
+                if (T * Hy > GSW_MAX_THREADS) break;
+                for (int trim = 0; trim < 2; ++trim) {          // ... and a sixth narrower (smaller LDS slice: one more resident workgroup)
+                    const int XG = std::min((T / DG) * (6 - trim) / 6, (W + GSW_RX - 1) / GSW_RX);
+                    if (XG < 2) continue;
+                    GswGeom g;
+                    if (!gsw_layout(g, win, XG, DG, Ty, 160 * 1024, Hy)) continue;
+                    g.nchunks = nch;
+                    bool dup = false;
+                    for (const GswGeom &o : out) dup = dup || (o.XG == g.XG && o.DG == g.DG && o.Ty == g.Ty && o.Hy == g.Hy && o.nchunks == g.nchunks);
+                    if (!dup && out.size() < 36) out.push_back(g);
+                }
+            }
+        }
+    }
 }
 
 int gsw_search_geometry(GswGeom &best, int W, int rows, int win, int nD)
@@ -1415,18 +1450,65 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.tab = d_tab;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.iterations = iterations; a.fMax = fMax;
-        const int TyS = a.g.Ty * a.g.Hy;
-        const dim3 grid((W + a.g.Tx - 1) / a.g.Tx, (rows + TyS - 1) / TyS, a.g.nchunks), block(a.g.threads * a.g.Hy);
-        auto kernel = a.g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
-        if ((rc = grant_dyn_lds(c, (const void *)kernel, a.g.lds_bytes))) return rc;
-        for (int pass = 0; pass < 2; ++pass) {
-            a.right = pass;
-            a.ref = (const uint32_t *)(pass ? c.recR.ptr : c.recL.ptr);
-            a.tgt = (const uint32_t *)(pass ? c.recL.ptr : c.recR.ptr);
-            a.key = (u64 *)(pass ? c.keyR.ptr : c.keyL.ptr);
+        // both passes with geometry g (the winner-take-all keys merge by atomicMin: repeated launches are idempotent)
+        auto launch = [&](const GswGeom &g) -> int {
+            a.g = g;
+            const int TyS = g.Ty * g.Hy;
+            const dim3 grid((W + g.Tx - 1) / g.Tx, (rows + TyS - 1) / TyS, g.nchunks), block(g.threads * g.Hy);
+            auto kernel = g.Ty == 2 ? gsw_aggregate_kernel<2, 4> : gsw_aggregate_kernel<1, 8>;
+            if (int grc = grant_dyn_lds(c, (const void *)kernel, g.lds_bytes)) return grc;
+            for (int pass = 0; pass < 2; ++pass) {
+                a.right = pass;
+                a.ref = (const uint32_t *)(pass ? c.recR.ptr : c.recL.ptr);
+                a.tgt = (const uint32_t *)(pass ? c.recL.ptr : c.recR.ptr);
+                a.key = (u64 *)(pass ? c.keyR.ptr : c.keyL.ptr);
+                hipLaunchKernelGGL(kernel, grid, block, g.lds_bytes, s, a);
+                HIP_TRY(hipGetLastError());
+            }
+            return SSAMD_OK;
+        };
+        // Autotuning (ssamd_autotune, as for ASW): the first call of a shape times the candidates of gsw_candidates on the
+        // call's own buffers -- three rounds in round-robin order, fastest launch of each -- and caches the winner.  Default
+        // mode: calls of at most 6e10 window taps (both passes; 2 lane-ops each: about 5 ms), where the model is least reliable.
+        {
+            const std::array<int, 4> shape{W, rows, win, nD};
+            const double call_taps = 2.0 * (double)W * rows * nD * win * win;
+            const int tune_mode = g_autotune.load();
+            bool tuned_already;
+            { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_gsw_geom_tuned.count(shape) != 0; }
+            if ((tune_mode > 0 || (tune_mode < 0 && call_taps <= 2.0 * ASW_AUTOTUNE_SMALL_TAPS)) && tune().gsw_geom.empty() && !tuned_already) {
+                std::vector<GswGeom> trial;
+                gsw_candidates(trial, a.g, W, rows, win, nD);
+                if (trial.size() >= 2) {
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    HIP_TRY(hipEventCreate(&e0));
+                    HIP_TRY(hipEventCreate(&e1));
+                    std::vector<float> cand_ms(trial.size(), 3.0e38f);
+                    for (int round = 0; round < 3; ++round)
+                        for (size_t ci = 0; ci < trial.size(); ++ci) {
+                            float ms = 3.0e38f;
+                            if (hipEventRecord(e0, s) == hipSuccess && launch(trial[ci]) == SSAMD_OK && hipEventRecord(e1, s) == hipSuccess &&
+                                hipEventSynchronize(e1) == hipSuccess)
+                                (void)hipEventElapsedTime(&ms, e0, e1);
+                            if (round > 0) cand_ms[ci] = std::min(cand_ms[ci], ms);      // round 0 is warm-up
+                        }
+                    GswGeom fastest = trial[0];
+                    float best_ms = 3.0e38f;
+                    for (size_t ci = 0; ci < trial.size(); ++ci)      // the model's own choice (first) keeps the job unless another is clearly faster
+                        if (cand_ms[ci] < best_ms * (ci == 0 ? 1.0f : 0.985f)) { best_ms = cand_ms[ci]; fastest = trial[ci]; }
+                    (void)hipEventDestroy(e0);
+                    (void)hipEventDestroy(e1);
+                    std::lock_guard<std::mutex> glk(g_geom_mutex);
+                    g_gsw_geom_cache[shape] = fastest;
+                    g_gsw_geom_tuned[shape] = true;
+                    a.g = fastest;
+                }
+            }
+        }
+        {
+            const GswGeom final_geom = a.g;
             Timed t(c, s, SSAMD_K_GSW_AGG);
-            hipLaunchKernelGGL(kernel, grid, block, a.g.lds_bytes, s, a);
-            HIP_TRY(hipGetLastError());
+            if ((rc = launch(final_geom))) return rc;
         }
     }
     return launch_finalize(c, SSAMD_K_GSW_FIN, true, rows, W, d_disp, s);   // consistency is unconditional in GSW

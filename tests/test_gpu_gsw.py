@@ -157,3 +157,30 @@ def test_gsw_1080p_config4_known_shift_and_strip_invariance(ss):
     h0, h1 = r0 - pad, r0 + rows + pad
     strip = m._compute_device(tL[h0:h1].contiguous(), tR[h0:h1].contiguous(), out_row0=r0 - h0, out_rows=rows)
     assert torch.equal(strip, d[r0:r0 + rows])
+
+
+def test_gsw_autotune_changes_the_geometry_never_the_map(ss, golden_cases, golden_inputs):
+    """ssamd_autotune applies to GSW as well (round 4): the first call of a shape times tiles of 2 / 4 / 8-row strips whose thread
+    groups fill whole waves and caches the fastest; every geometry accumulates each output row's taps in the reference's raster
+    order, so the map is the reference's whatever wins"""
+    import torch
+    from simplestereo_amd.synth import make_pair
+    maps, _ = golden_cases
+    lib = _native.lib()
+    a, b = golden_inputs("synth_64x96")
+    L, R, _ = make_pair(200, 700, 40, 4)
+    prev = lib.ssamd_autotune(0)
+    try:
+        m = ss.passive.StereoGSW(winSize=11, maxDisparity=24, minDisparity=0)
+        big = ss.passive.StereoGSW(winSize=11, maxDisparity=16)
+        want, want_big = m.compute(a, b), big.compute(L, R)
+        g0 = _native.gsw_geometry(700, 200, 11, 16, 0)
+        lib.ssamd_autotune(1)
+        got, got_big = m.compute(a, b), big.compute(L, R)
+        again = big.compute(L, R)
+        g1 = _native.gsw_geometry(700, 200, 11, 16, 0)
+    finally:
+        lib.ssamd_autotune(prev)
+    print("model", g0, "tuned", g1)
+    assert np.array_equal(got, want) and np.array_equal(got, maps["G6d"])
+    assert np.array_equal(got_big, want_big) and np.array_equal(again, want_big)
