@@ -70,6 +70,7 @@ CONFIGS = {
 GSW_CONFIGS = {
     # BASELINE config 4: StereoGSW class defaults (winSize 11, gamma 10, fMax 120, iterations 3) at 1080p / D 0..192
     "c4_gsw_1080p_d192_w11": (1080, 1920, 192, 0, 11),
+    "default_gsw_1080p_d16_w11": (1080, 1920, 16, 0, 11),      # StereoGSW() class defaults (passive.py:133-134) on a 1080p frame
 }
 GAMMA_C, GAMMA_P = 5.0, 17.5
 GSW_GAMMA, GSW_FMAX, GSW_ITER = 10, 120.0, 3
@@ -339,7 +340,7 @@ def others(dev, seed):
             res[name] = {"matcher": "StereoGSW (+ left-right check and fill, always on)", "H": H, "W": W, "maxDisparity": maxD,
                          "minDisparity": minD, "winSize": win, "gamma": GSW_GAMMA, "fMax": GSW_FMAX, "iterations": GSW_ITER,
                          "ms_per_step": wall, "value": H * W * nD / (wall * 1e-3) / 1e6, "unit": "MPixels*disp/s",
-                         "checksum": checksum,
+                         "checksum": checksum, "launch": _native.gsw_geometry(W, H, win, maxD, minD),
                          "roofline": {"bound": "valu", "kernel": "gsw_aggregate_kernel (all launches of a step)", "kernel_ms": k_ms,
                                       "taps": taps, "lane_ops_per_tap": GSW_OPS_PER_TAP, "tap_instructions": GSW_TAP_INSTRUCTIONS,
                                       "achieved": achieved, "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s",
