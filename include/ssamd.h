@@ -158,6 +158,13 @@ int ssamd_asw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int
                                int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
                                double gammaC, double gammaP, int consistent, int16_t *d_disparity, void *stream);
 
+/* The same for StereoGSW (_rigs.py:543-567 feeding passive.py:153): raw frames through the rig's maps straight into the
+ * matcher's packed pixels, one launch for both images. */
+int ssamd_gsw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
+                               const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
+                               int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
+                               int gamma, float fMax, int iterations, int bins, int16_t *d_disparity, void *stream);
+
 /* RectifiedStereoRig.get3DPoints (reference _rigs.py:569-628 = cv2.reprojectImageTo3D):
  * d_points float32 [h][w][3] from int16 disparities and the 4x4 matrix Q (16 doubles, row
  * major, HOST memory).  h <= 65535; when w is a multiple of 4 (four pixels per thread) d_disparity must be 8-byte and

@@ -113,6 +113,8 @@ def lib():
     L.ssamd_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.ssamd_asw_rectified_device.restype = I
     L.ssamd_asw_rectified_device.argtypes = [P, P, I, I, P, P, P, P, I, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_gsw_rectified_device.restype = I
+    L.ssamd_gsw_rectified_device.argtypes = [P, P, I, I, P, P, P, P, I, I, I, I, I, I, I, F, I, I, P, P]
     L.ssamd_counter.restype = I
     L.ssamd_counter.argtypes = [I, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]
     _lib = L

@@ -114,6 +114,21 @@ __global__ __launch_bounds__(256) void remap_lab_records_pair_kernel(const Remap
     }
 }
 
+// The same for GSW, which works on the raw colour bytes (_passive.cpp:740-741): remap + pack (B | G << 8 | R << 16) of both images.
+__global__ __launch_bounds__(256) void remap_pack_pair_kernel(const RemapSrc S, uint32_t *__restrict__ outL, uint32_t *__restrict__ outR,
+                                                              long long pix0, long long npix)
+{
+    const size_t src_bytes = (size_t)S.Hs * S.Ws * 3;
+    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; q < 2 * npix; q += stride) {
+        const bool right = q >= npix;
+        const long long p = pix0 + (right ? q - npix : q);
+        (right ? outR : outL)[p] = remap_pixel(right ? S.src2 : S.src1, S.Hs, S.Ws, src_bytes, (right ? S.mapx2 : S.mapx1)[p],
+                                              (right ? S.mapy2 : S.mapy1)[p], S.nearest);
+    }
+}
+
 struct Mat4 {
     double m[16];
 };

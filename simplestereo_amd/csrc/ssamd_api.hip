@@ -1417,7 +1417,7 @@ int get_gsw_table(Ctx &c, int gamma, hipStream_t s, const float **out)
 }
 
 int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win, int maxD,
-                    int minD, int gamma, float fMax, int iterations, int16_t *d_disp, hipStream_t s)
+                    int minD, int gamma, float fMax, int iterations, int16_t *d_disp, hipStream_t s, const RemapSrc *rm = nullptr)
 {
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
@@ -1439,10 +1439,15 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         const int blocks = (int)std::min<long long>((np + 255) / 256, 256 * 8);
         {
             Timed t(c, s, SSAMD_K_LAB);
-            hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3,
-                               (uint32_t *)c.recL.ptr + (size_t)r0 * W, np);
-            hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dR + (size_t)r0 * W * 3,
-                               (uint32_t *)c.recR.ptr + (size_t)r0 * W, np);
+            if (rm) {       // raw frames through the rig's maps: rectification + packing of both images, one launch
+                hipLaunchKernelGGL(remap_pack_pair_kernel, dim3(blocks), dim3(256), 0, s, *rm, (uint32_t *)c.recL.ptr, (uint32_t *)c.recR.ptr,
+                                   (long long)r0 * W, np);
+            } else {
+                hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3,
+                                   (uint32_t *)c.recL.ptr + (size_t)r0 * W, np);
+                hipLaunchKernelGGL(bgr_pack_kernel, dim3(blocks), dim3(256), 0, s, dR + (size_t)r0 * W * 3,
+                                   (uint32_t *)c.recR.ptr + (size_t)r0 * W, np);
+            }
             HIP_TRY(hipGetLastError());
         }
         GswArgs a;
@@ -1903,6 +1908,25 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
     if (rc) return rc;
     return gsw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gamma, fMax, iterations, d_disparity, (hipStream_t)stream);
+}
+
+int ssamd_gsw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
+                               const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
+                               int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
+                               int gamma, float fMax, int iterations, int bins, int16_t *d_disparity, void *stream)
+{
+    (void)bins;
+    if (!d_raw1 || !d_raw2 || !d_mapx1 || !d_mapy1 || !d_mapx2 || !d_mapy2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (src_height <= 0 || src_width <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (interpolation != 0 && interpolation != 1) return fail(SSAMD_EINVAL, "only INTER_NEAREST (0) and INTER_LINEAR (1) are supported");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    RemapSrc rm;
+    rm.src1 = d_raw1; rm.src2 = d_raw2; rm.mapx1 = d_mapx1; rm.mapy1 = d_mapy1; rm.mapx2 = d_mapx2; rm.mapy2 = d_mapy2;
+    rm.Hs = src_height; rm.Ws = src_width; rm.nearest = interpolation == 0 ? 1 : 0;
+    return gsw_device_impl(*c, nullptr, nullptr, height, width, 0, height, winSize, maxDisparity, minDisparity, gamma, fMax, iterations,
+                           d_disparity, (hipStream_t)stream, &rm);
 }
 
 int ssamd_gsw(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,

@@ -349,9 +349,15 @@ class StereoGSW():
         return (_c_int(self.winSize), _c_int(self.maxDisparity), _c_int(self.minDisparity), _c_int(self.gamma),
                 _c_double(self.fMax), _c_int(self.iterations), _c_int(self.bins))
 
-    def compute(self, img1, img2, devices=None):
+    def compute(self, img1, img2, devices=None, rectify=None, interpolation=1):
         """Disparity map of a rectified 3-channel pair (uint8 [H,W,3]); returns int16 [H,W].
-        ``devices`` (extension, host arrays only): list of GPU indices that share the frame as row strips."""
+        ``devices`` (extension, host arrays only): list of GPU indices that share the frame as row strips.
+        ``rectify`` (extension, device tensors only): a ``RectifiedStereoRig`` with computed maps -- ``img1`` / ``img2`` are then
+        the RAW frames, rectified and matched in one call (see ``StereoASW.compute``); same map as the two calls."""
+        if rectify is not None:
+            if not (_is_device_tensor(img1) and _is_device_tensor(img2)) or devices is not None:
+                raise ValueError("rectify=rig applies to two device tensors (raw frames resident in HBM)")
+            return self._compute_rectified_device(rectify, img1, img2, interpolation)
         if _is_device_tensor(img1) and _is_device_tensor(img2):
             if devices is not None:
                 raise ValueError("devices=[...] applies to host arrays; device tensors are matched where they live")
@@ -376,6 +382,35 @@ class StereoGSW():
                                         out.ctypes.data, dev))
         except _native.NativeError as e:
             _raise_native(e)
+        return out
+
+    def _compute_rectified_device(self, rig, raw1, raw2, interpolation=1):
+        """raw frames -> (rectification + pixel packing in one launch) -> matcher: ssamd_gsw_rectified_device"""
+        import torch
+        lib = _native.lib()
+        win, maxd, mind, gamma, fmax, it, bins = self._params()
+        a, b = _check_pair_tensors(raw1, raw2)
+        if not (win > 0 and win % 2 == 1):
+            raise ValueError("winSize must be a positive odd number!")
+        if interpolation not in (0, 1):
+            raise NotImplementedError("only INTER_NEAREST (0) and INTER_LINEAR (1) are available")
+        if getattr(rig, "mapx1", None) is None:
+            raise ValueError("the rig has no rectification maps: call computeRectificationMaps() first")
+        mx1, my1 = rig._device_maps(1, a.device)
+        mx2, my2 = rig._device_maps(2, a.device)
+        if mx1.shape != mx2.shape:
+            raise ValueError("Wrong image dimensions!")
+        H, W = int(mx1.shape[0]), int(mx1.shape[1])
+        out = torch.empty((H, W), dtype=torch.int16, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            try:
+                _native.check(lib.ssamd_gsw_rectified_device(a.data_ptr(), b.data_ptr(), int(a.shape[0]), int(a.shape[1]),
+                                                             mx1.data_ptr(), my1.data_ptr(), mx2.data_ptr(), my2.data_ptr(), H, W,
+                                                             int(interpolation), win, maxd, mind, gamma, fmax, it, bins, out.data_ptr(),
+                                                             ctypes.c_void_p(stream)))
+            except _native.NativeError as e:
+                _raise_native(e)
         return out
 
     def _compute_device(self, t1, t2, out_row0=0, out_rows=None):

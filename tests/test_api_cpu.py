@@ -41,9 +41,9 @@ def test_signatures_match_reference(ss):
     assert (m.winSize, m.maxDisparity, m.minDisparity, m.gammaC, m.gammaP, m.consistent) == (7, 3, 0, 5, 17.5, False)
     g = ss.passive.StereoGSW()
     assert (g.winSize, g.gamma, g.maxDisparity, g.minDisparity, g.fMax, g.iterations, g.bins) == (11, 10, 16, 0, 120, 3, 20)
-    # compute(img1, img2) of the reference (passive.py:72, 147) + optional trailing keywords: devices=None, and for ASW
+    # compute(img1, img2) of the reference (passive.py:72, 147) + optional trailing keywords: devices=None,
     # rectify=None / interpolation=1 (rectification + matching in one call)
-    for cls, extra in ((ss.passive.StereoASW, ["rectify", "interpolation"]), (ss.passive.StereoGSW, [])):
+    for cls, extra in ((ss.passive.StereoASW, ["rectify", "interpolation"]), (ss.passive.StereoGSW, ["rectify", "interpolation"])):
         params = inspect.signature(cls.compute).parameters
         assert list(params) == ["self", "img1", "img2", "devices"] + extra and params["devices"].default is None
     assert inspect.signature(ss.passive.StereoASW.compute).parameters["rectify"].default is None

@@ -162,6 +162,8 @@ def test_rectify_and_match_in_one_call(dest, params, interp, env):
     fused = m.compute(tL, tR, rectify=rig, interpolation=interp)
     assert fused.is_cuda and fused.dtype == torch.int16 and tuple(fused.shape) == (dest[1], dest[0])
     assert torch.equal(fused, two_step)
+    g = ss.passive.StereoGSW(winSize=min(params["winSize"], 11), maxDisparity=params["maxDisparity"], minDisparity=params.get("minDisparity", 0))
+    assert torch.equal(g.compute(tL, tR, rectify=rig, interpolation=interp), g.compute(*rig.rectifyImages(tL, tR, interpolation=interp)))
     with pytest.raises(ValueError):
         m.compute(L, R, rectify=rig)                      # host arrays: the two-step path is the one to use
     with pytest.raises(ValueError):
