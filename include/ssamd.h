@@ -234,8 +234,8 @@ int ssamd_counter(int device, const char *name, long long *value);
  * rows, winSize, number of disparities) times the best tile of every class of candidates on the call's own
  * buffers -- up to ten candidates, five launches each in round-robin order, once -- and later calls reuse the
  * fastest.  The disparity maps do not depend on the geometry.  on = 1: always; 0: never; -1 (the default, also
- * SSAMD_AUTOTUNE=-1): only for calls of at most 3e10 window taps (3-4 ms of kernel time: VGA / 720p frames,
- * small disparity ranges), where the trial launches cost at most ~0.2 s once and the cost model is least reliable.  The environment
+ * SSAMD_AUTOTUNE=-1): only for calls of at most 6e10 window taps (6-8 ms of kernel time: VGA / 720p frames,
+ * small disparity ranges), where the trial launches cost at most ~0.4 s once and the cost model is least reliable.  The environment
  * variable SSAMD_AUTOTUNE=1 / 0 / -1 sets the initial mode.  Returns the previous mode.
  * Since ABI version 3 the same mode governs ssamd_gsw*: the first GSW call of a shape of at most 6e10 window taps (both passes)
  * times strips of 2 / 4 / 8 output rows whose thread groups fill whole waves, three launches each, and caches the fastest. */

@@ -647,9 +647,9 @@ int asw_search_geometry(AswGeom &best, int W, int rows, int win, int nD, std::ve
 std::map<std::array<int, 4>, AswGeom> g_asw_geom_cache;
 std::map<std::array<int, 4>, bool> g_asw_geom_tuned;      // shapes whose cached geometry was picked by measurement
 // autotuning mode: 1 always, 0 never, -1 (default) only for small problems, where the ~50 trial launches cost
-// at most about 0.2 s once and where the cost model is least reliable
+// at most about 0.4 s once and where the cost model is least reliable
 std::atomic<int> g_autotune{g_tuning.autotune_env != -2 ? g_tuning.autotune_env : -1};
-constexpr double ASW_AUTOTUNE_SMALL_TAPS = 3.0e10;      // window taps per call (about 3-4 ms of kernel time)
+constexpr double ASW_AUTOTUNE_SMALL_TAPS = 6.0e10;      // window taps per call (about 6-8 ms of kernel time; 3e10 until round 4)
 
 // experiment / test hooks that force a kernel form: such calls neither read nor write the geometry cache and are not autotuned
 bool asw_geometry_forced()
@@ -1481,7 +1481,7 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             const int tune_mode = g_autotune.load();
             bool tuned_already;
             { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_gsw_geom_tuned.count(shape) != 0; }
-            if ((tune_mode > 0 || (tune_mode < 0 && call_taps <= 2.0 * ASW_AUTOTUNE_SMALL_TAPS)) && tune().gsw_geom.empty() && !tuned_already) {
+            if ((tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS)) && tune().gsw_geom.empty() && !tuned_already) {
                 std::vector<GswGeom> trial;
                 gsw_candidates(trial, a.g, W, rows, win, nD);
                 if (trial.size() >= 2) {

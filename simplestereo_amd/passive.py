@@ -125,8 +125,8 @@ def _device_list(devices):
 def set_autotune(on=True):
     """Extension: launch-geometry autotuning of ``StereoASW``.  ``True``: the first ``compute`` call of every
     problem shape times its candidate geometries on the GPU (up to ~50 extra kernel launches, once) instead of
-    trusting the cost model; ``False``: never; ``None``: the default -- only for small calls (at most 3e10 window
-    taps, i.e. a few milliseconds of kernel time), where that costs at most ~0.2 s once.  Maps are unaffected:
+    trusting the cost model; ``False``: never; ``None``: the default -- only for small calls (at most 6e10 window
+    taps, i.e. a few milliseconds of kernel time), where that costs at most ~0.4 s once.  Maps are unaffected:
     every geometry accumulates the same taps in the same order.  Returns the previous mode (True / False / None).
     The environment variable ``SSAMD_AUTOTUNE=1 / 0 / -1`` sets the initial mode."""
     before = _native.lib().ssamd_autotune(-1 if on is None else (1 if on else 0))
