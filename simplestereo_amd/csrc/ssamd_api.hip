@@ -69,6 +69,7 @@ struct Tuning {
     int alt_queue_cap = 0;            // 0 unset
     int autotune_env = -2;            // -2 unset
     int evol_fail = 0;                // test hook: 1 = the TAD volume's allocation really fails (a hipMalloc no device can serve)
+    int lds_relax = 1;                // 0: a phase-shifted tile must fit LDS with its staged colour bytes even when the TAD volume makes them unnecessary
     int wave_creg = 1;                // 0: the wave kernel keeps its window centres in LDS (round-3 form)
     int asw_tail = -1;                // -1: the host decides; 0: never split the last partial round of workgroups into half-width tiles; 1: whenever possible
 };
@@ -99,6 +100,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_EVOL_FAIL") t.evol_fail = num(0);
     else if (name == "SSAMD_ASW_TAIL") t.asw_tail = num(-1);
     else if (name == "SSAMD_ASW_WAVE_CREG") t.wave_creg = num(1);
+    else if (name == "SSAMD_ASW_LDS_RELAX") t.lds_relax = num(1);
     else return false;
     return true;
 }
@@ -106,7 +108,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
-                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG"};
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG", "SSAMD_ASW_LDS_RELAX"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -338,6 +340,8 @@ int check_common(int H, int W, int win, int minD, int maxD, int row0, int rows)
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ------------------------------------------------------------ ASW geometry
+thread_local bool t_pipe_full_lds = false;      // true while a geometry is planned for a call that has no TAD volume
+
 bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int Rx, bool e2, bool odd_pitch = false,
                   bool pipe = false)
 {
@@ -430,6 +434,9 @@ bool asw_layout_e(AswGeom &g, int win, int XG, int DG, size_t limit, int JC, int
         g.off_bgrR = take((size_t)g.nR * 4 * 2);
     }
     g.lds_bytes = (int)off;
+    // the phase-shifted kernel normally runs with the TAD volume and then does not allocate the staged colour bytes: a tile may
+    // count on that (round 4); a call that cannot have the volume re-plans with t_pipe_full_lds set (asw_device_impl)
+    if (g.pipe && tune().asw_evol != 0 && tune().lds_relax != 0 && !t_pipe_full_lds) return (size_t)g.lds_bytes_evol <= limit;
     return off <= limit;
 }
 
@@ -657,7 +664,7 @@ bool asw_geometry_forced()
     const Tuning &t = tune();
     return !t.asw_geom.empty() || t.asw_wave >= 0 || t.wave_rx != 0 || t.wave_merge != 1 || t.asw_pipe >= 0 || t.asw_dephase >= 0 ||
            t.asw_evol != 1 || t.wave_wg != 0 || t.no_e2 || t.xor_only || t.asw_static != 1 || t.evol_max_mb != 0 || t.wave_rd != 0 ||
-           t.wave_creg != 1;
+           t.wave_creg != 1 || t.lds_relax != 1;
 }
 
 int asw_choose_geometry(AswGeom &best, int W, int rows, int win, int nD)
@@ -1093,6 +1100,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                     else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = asw_aggregate_pipe_kernel<false, 216, 284, 80>;
                 }
                 const int pipe_lds = a.evol ? g.lds_bytes_evol : g.lds_bytes;          // (no staged colour bytes when the e tiles come from the volume)
+                if (pipe_lds > 160 * 1024) return fail(SSAMD_ELIMIT, "this tile needs the TAD volume (LDS %d bytes without it)", pipe_lds);
                 if (int grc = grant_dyn_lds(c, (const void *)pk, pipe_lds)) return grc;
                 // The last PARTIAL round of workgroups (round 4).  The kernel keeps one 12-wave workgroup per CU, so a launch
                 // of n workgroups takes ceil(n / 256) rounds: a row strip of an 8-GPU run (135 rows x 16 tiles = 8.44 rounds)
@@ -1185,8 +1193,24 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.g = fastest;
         }
         {
-            const AswGeom final_geom = a.g;
+            AswGeom final_geom = a.g;
             if ((rc = prepare_evol(final_geom))) return rc;
+            if (final_geom.pipe && !final_geom.wave_rx && !a.evol && final_geom.lds_bytes > 160 * 1024) {
+                // the tile was planned on the TAD volume (no staged colour bytes in LDS) and the volume cannot be had: plan
+                // again for the in-kernel e tiles (asw_layout_e: t_pipe_full_lds)
+                t_pipe_full_lds = true;
+                AswGeom g2;
+                const int r2 = asw_search_geometry(g2, W, grows, win, nD);
+                t_pipe_full_lds = false;
+                if (r2) return r2;
+                g2.wave_rx = 0;
+                if (!is_direct(g2) && !need_keys) {
+                    if ((rc = c.keyL.reserve(nout * 8))) return rc;
+                    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+                }
+                final_geom = g2;
+                if ((rc = prepare_evol(final_geom))) return rc;
+            }
             Timed t(c, s, SSAMD_K_ASW_AGG);
             if ((rc = launch(final_geom))) return rc;
         }

@@ -383,7 +383,9 @@ def test_autotune_changes_the_geometry_never_the_map(ss, golden_inputs):
 
 
 @pytest.mark.parametrize("shape,win,maxd,consistent", [((48, 200), 35, 60, False), ((48, 200), 35, 70, True), ((40, 300), 21, 16, True),
-                                                       ((30, 2000), 35, 192, False)])
+                                                       ((30, 2000), 35, 192, False),
+                                                       # tiles planned on the volume (their LDS only fits without the staged colour bytes): re-planned
+                                                       ((30, 1920), 35, 64, False), ((24, 1920), 35, 128, True)])
 def test_asw_without_room_for_the_tad_volume(shape, win, maxd, consistent, ss):
     """when the device has no room for the pre-computed TAD volume (here: the cap forced down to 1 MiB) the phase-shifted
     kernel builds its e tiles itself and a small range falls back from the wave kernel to the workgroup kernels: same maps"""
