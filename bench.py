@@ -103,98 +103,161 @@ def count_taps(H, W, win, maxD, minD, row0=0, rows=None):
     return int(vrows.sum()) * int(cols.sum())
 
 
-def cpu_baseline(cfg, seed, rows_per_thread=1, timeout_s=900, crop_cols=512, repeats=2):
+def cpu_baseline(cfg, seed, rows_per_thread=1, timeout_s=300, crop_cols=512, repeats=2, pin_cores=32, pinned_rows_per_core=4):
     """Time the reference (and the hoisted plain-C port) on a bounded crop of the same frame, on the host cores.
 
-    The reference hands out ONE image row per job to hardware_concurrency() threads (_passive.cpp:352-355, 372-396),
-    so a sample keeps every host thread busy only if it has at least as many rows as there are threads: the sample is
-    the centre `rows_per_thread x threads` rows of the frame.  To keep that within the 10-30 s of CPU work the bench
-    contract allows (the reference does ~1e9 window taps per second on 256 threads; a full-width 1080p strip of 512
-    rows took 190-215 s, profiles/r02_b_bench_full_cpu_strip.json), the rows are cropped to the centre `crop_cols`
-    columns: equal-cost row jobs, one or more per thread, scaled to the full frame by the exact tap count."""
+    The reference hands out ONE image row per job to hardware_concurrency() threads (_passive.cpp:352-355, 372-396).
+    Two samples, both cropped to the centre `crop_cols` columns (equal-cost row jobs) and scaled to the full frame by
+    the exact tap count:
+
+    * HEADLINE (`value`, `cores`): the process is pinned (os.sched_setaffinity, before the reference is loaded: its
+      hardware_concurrency() follows the affinity mask) to `pin_cores` CPUs on distinct physical cores and matches
+      `pinned_rows_per_core` row jobs per core, so the one-row-per-thread queue is neither starved nor oversubscribed
+      and the denominator has a stated core count.  Timed `repeats` times.
+    * `all_threads`: every visible host thread, `rows_per_thread` row jobs each (what rounds 1-4 reported as the
+      headline; on these shared 256-thread hosts it measured ~18 core-equivalents).  Timed once.
+
+    Every run records process CPU seconds (RUSAGE_SELF covers the reference's threads), the affinity count and the
+    cgroup CPU quota, so `effective_cores` = cpu_s / wall_s says how many cores actually worked."""
     H, W, maxD, minD, win = cfg
     cols = min(W, crop_cols)
     c0 = (W - cols) // 2
     code = r"""
-import sys, time, json, os
+import sys, time, json, os, resource
 sys.path.insert(0, %r)
+rows, path, mode, c0, cols, pin = int(sys.argv[1]), sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+aff0 = sorted(os.sched_getaffinity(0))
+pinned = None
+if pin > 0:
+    # one CPU per physical core first (SMT siblings share the FMA pipes), then siblings if there are not enough cores
+    seen, first, rest = set(), [], []
+    for c in aff0:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%%d/topology/thread_siblings_list" %% c).read().strip()
+        except OSError:
+            sib = str(c)
+        (rest if sib in seen else first).append(c)
+        seen.add(sib)
+    pinned = (first + rest)[:pin]
+    os.sched_setaffinity(0, pinned)
 import numpy as np
 from oracle import oracle
 from simplestereo_amd.synth import make_pair
-H, W, maxD, minD, win, rows, seed = %d, %d, %d, %d, %d, int(sys.argv[1]), %d
-mode = sys.argv[3]
+H, W, maxD, minD, win, seed = %d, %d, %d, %d, %d, %d
 L, R, _ = make_pair(H, W, maxD, seed)
 r0 = (H - rows) // 2
-c0, cols = int(sys.argv[4]), int(sys.argv[5])
 a, b = np.ascontiguousarray(L[r0:r0 + rows, c0:c0 + cols]), np.ascontiguousarray(R[r0:r0 + rows, c0:c0 + cols])
 ref = oracle.ref_module() if mode == "reference" else None
 oracle.asw(a[:2, :64], b[:2, :64], 5, 4, 0, %r, %r)       # load the library outside the timed region
+try:
+    quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+except OSError:
+    quota = None
+ru0 = resource.getrusage(resource.RUSAGE_SELF)
 t = time.time()
 if mode == "hoisted":
-    d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=True); kind = "port-hoisted"
+    d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=True, nthreads=len(os.sched_getaffinity(0))); kind = "port-hoisted"
 elif ref is not None:
     d = ref.computeASW(a, b, win, maxD, minD, %r, %r, False); kind = "reference"
 else:
-    d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=False); kind = "port"
+    d = oracle.asw(a, b, win, maxD, minD, %r, %r, False, hoist=False, nthreads=len(os.sched_getaffinity(0))); kind = "port"
 dt = time.time() - t
-np.save(sys.argv[2], d)
-print(json.dumps({"t": dt, "kind": kind, "cores": os.cpu_count(), "r0": int(r0)}))
+ru1 = resource.getrusage(resource.RUSAGE_SELF)
+np.save(path, d)
+print(json.dumps({"t": dt, "kind": kind, "r0": int(r0), "cpu_s": (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime),
+                  "host_threads_visible": os.cpu_count(), "affinity_cpus": len(aff0), "pinned_cpus": pinned,
+                  "threads_used": len(os.sched_getaffinity(0)), "cgroup_cpu_max": quota,
+                  "worker_threads": os.cpu_count() if kind == "reference" else len(os.sched_getaffinity(0))}))
 """ % (ROOT, H, W, maxD, minD, win, seed, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P, GAMMA_C, GAMMA_P)
 
     import tempfile
     dump = os.path.join(tempfile.gettempdir(), "ssamd_cpu_ref_%d.npy" % os.getpid())
+    dump_a = os.path.join(tempfile.gettempdir(), "ssamd_cpu_all_%d.npy" % os.getpid())
     dump_h = os.path.join(tempfile.gettempdir(), "ssamd_cpu_hoist_%d.npy" % os.getpid())
 
-    def run(rows, mode, path):
-        out = subprocess.run([sys.executable, "-c", code, str(rows), path, mode, str(c0), str(cols)], capture_output=True,
+    def run(rows, mode, path, pin):
+        out = subprocess.run([sys.executable, "-c", code, str(rows), path, mode, str(c0), str(cols), str(pin)], capture_output=True,
                              text=True, timeout=timeout_s)      # the reference's queue has an empty()/pop() race: bounded wait
         res = json.loads(out.stdout.strip().splitlines()[-1])
         res["rows"] = rows
         return res
 
-    cores = os.cpu_count() or 1
-    rows = min(H, max(rows_per_thread * cores, 8))
+    try:
+        navail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        navail = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
+    npin = max(1, min(pin_cores, navail))
+    # The reference spawns std::thread::hardware_concurrency() threads -- on glibc 2.35 that is the number of ONLINE CPUs
+    # whatever the affinity mask says (probed: taskset -c 0,1 still reports all) -- and its queue hands a row to every thread
+    # that saw the queue non-empty: with fewer rows than threads the threads left over block in SafeQueue::pop for ever
+    # (safequeue.hpp:106-114, _passive.cpp:29-32).  So every sample has at least as many rows as there are online CPUs; the
+    # pinned sample's threads are then time-sliced on `npin` cores, and effective_cores says what they got.
+    rows_pin = min(H, max(pinned_rows_per_core * npin, visible, 8))
+    rows_all = min(H, max(rows_per_thread * navail, visible, 8))
     full = count_taps(H, W, win, maxD, minD)
-    taps = count_taps(rows, cols, win, maxD, minD)       # the crop is matched as a stand-alone sub-image
     nD = maxD - minD + 1
 
     def entry(res):
-        t_full = res["t"] * full / taps                  # per-tap cost is uniform
-        return {"value": H * W * nD / t_full / 1e6, "unit": "MPixels*disp/s", "cores": res["cores"], "kind": res["kind"],
+        rows = res["rows"]
+        taps = count_taps(rows, cols, win, maxD, minD)       # the crop is matched as a stand-alone sub-image
+        t_full = res["t"] * full / taps                      # per-tap cost is uniform
+        used = res["threads_used"]
+        eff = res["cpu_s"] / res["t"] if res["t"] > 0 else None
+        return {"value": H * W * nD / t_full / 1e6, "unit": "MPixels*disp/s", "cores": used, "kind": res["kind"],
+                "host_threads_visible": res["host_threads_visible"], "affinity_cpus": res["affinity_cpus"],
+                "pinned_cpus": res["pinned_cpus"], "cgroup_cpu_max": res["cgroup_cpu_max"], "worker_threads": res["worker_threads"],
                 "strip_row0": res["r0"], "strip_rows": rows, "strip_col0": c0, "strip_cols": cols,
-                "threads_busy": min(rows, res["cores"]),
-                "rows_per_thread": rows / float(res["cores"]), "wall_s": res["t"],
-                "sample": "%dx%d centre crop (%d rows = %.1f row jobs per host thread, %d of %d columns) of the same frame, "
-                          "%.3g of the frame's %.4g window taps, %.1f s wall on %d host threads; scaled to the full frame by "
-                          "exact tap count" %
-                          (cols, rows, rows, rows / float(res["cores"]), cols, W, taps / full, float(full), res["t"], res["cores"])}
+                "rows_per_thread": rows / float(used), "wall_s": res["t"], "cpu_s": res["cpu_s"],
+                "effective_cores": eff, "taps": taps, "taps_per_s": taps / res["t"],
+                "taps_per_s_per_effective_core": taps / res["cpu_s"] if res["cpu_s"] > 0 else None,
+                "sample": "%dx%d centre crop (%d rows = %.1f row jobs per CPU on %d CPUs%s, %d of %d columns) of the same "
+                          "frame, %.3g of the frame's %.4g window taps, %.1f s wall / %.1f CPU-s (%.1f effective cores); scaled to "
+                          "the full frame by exact tap count" %
+                          (cols, rows, rows, rows / float(used), used,
+                           " pinned to %d CPUs on distinct physical cores" % len(res["pinned_cpus"]) if res["pinned_cpus"] else
+                           " = every CPU of the affinity mask", cols, W, taps / full, float(full), res["t"], res["cpu_s"], eff or 0.0)}
     try:
-        # the denominator is noisy on these hosts (0.69-1.5 MP*disp/s for the same code across boxes and rounds: 256 SMT
-        # threads, whatever else the host runs): the sample is timed `repeats` times and the spread reported
         load0 = os.getloadavg()
-        runs = [entry(run(rows, "reference", dump)) for _ in range(max(1, repeats))]
+        runs = [entry(run(rows_pin, "reference", dump, npin)) for _ in range(max(1, repeats))]
         cb = dict(runs[0])
         vals = [r["value"] for r in runs]
         cb["value"] = sum(vals) / len(vals)
         cb["value_min"], cb["value_max"] = min(vals), max(vals)
-        cb["runs"] = [{"value": r["value"], "wall_s": r["wall_s"]} for r in runs]
+        cb["runs"] = [{"value": r["value"], "wall_s": r["wall_s"], "cpu_s": r["cpu_s"], "effective_cores": r["effective_cores"]} for r in runs]
         cb["wall_s"] = sum(r["wall_s"] for r in runs)
-        cb["host_loadavg_before"], cb["host_loadavg_after"] = list(load0), list(os.getloadavg())
+        cb["cpu_s"] = sum(r["cpu_s"] for r in runs)
+        cb["effective_cores"] = cb["cpu_s"] / cb["wall_s"]
+        cb["taps_per_s_per_effective_core"] = sum(r["taps"] for r in runs) / cb["cpu_s"]
+        # the same rate expressed per core in the metric's unit: what ONE busy core of this host delivers
+        cb["value_per_effective_core"] = cb["value"] / cb["effective_cores"]
+        cb["host_loadavg_before"] = list(load0)
         cb["sample"] += "; timed %d times, value = mean, value_min / value_max = the spread" % len(runs)
         cb["map_file"] = dump
     except Exception as e:      # noqa: BLE001  -- the baseline must never sink the bench line
-        return {"value": None, "unit": "MPixels*disp/s", "cores": cores, "kind": "unavailable", "sample": repr(e)[:200]}
+        return {"value": None, "unit": "MPixels*disp/s", "cores": npin, "host_threads_visible": visible, "kind": "unavailable",
+                "sample": repr(e)[:200]}
+    try:
+        # what rounds 1-4 reported: every visible host thread, one row job each (oversubscribed on a loaded shared host)
+        ab = entry(run(rows_all, "reference", dump_a, 0))
+        os.remove(dump_a)
+        ab["value_per_effective_core"] = ab["value"] / ab["effective_cores"] if ab["effective_cores"] else None
+        cb["all_threads"] = ab
+    except Exception as e:      # noqa: BLE001
+        cb["all_threads"] = {"value": None, "kind": "unavailable", "sample": repr(e)[:200]}
     try:
         # the second comparison BASELINE.md section 3 asks for: a CPU mode with the SAME algebraic shortcut as the GPU
         # kernels (the other image's support weights evaluated once per pixel and window row instead of once per
-        # candidate; bit-identical maps, tests/test_oracle_golden.py)
-        hb = entry(run(rows, "hoisted", dump_h))
+        # candidate; bit-identical maps, tests/test_oracle_golden.py); same pinning and rows as the headline sample
+        hb = entry(run(rows_pin, "hoisted", dump_h, npin))
         import numpy as np
         hb["map_equals_reference_map"] = bool(np.array_equal(np.load(dump), np.load(dump_h)))
         os.remove(dump_h)
+        hb["value_per_effective_core"] = hb["value"] / hb["effective_cores"] if hb["effective_cores"] else None
         cb["hoisted"] = hb
     except Exception as e:      # noqa: BLE001
         cb["hoisted"] = {"value": None, "kind": "unavailable", "sample": repr(e)[:200]}
+    cb["host_loadavg_after"] = list(os.getloadavg())
     return cb
 
 
@@ -353,12 +416,15 @@ def others(dev, seed):
     return res
 
 
-def bad1_on_reference_strips(dev, rank=0, world=1):
-    """GPU maps of the committed full-width reference strips (tests/golden/wide_cases.*: the config-3 frames; and
-    tests/golden/photo_cases.*: the lawn pair of the reference's own ASW example at native width, D 4..100) against the
-    maps of the unmodified reference: 0 s of CPU time.  With world > 1 every case goes through a StripContext over all
-    ranks (row strips + RCCL halo exchange + all-gather, the path the timed region ran) -- every rank must call this;
-    rank 0 gets the figures."""
+def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
+    """The accuracy half of BASELINE.json's metric.  HEADLINE (`percent`, `exact_percent`, `pixels`): the GPU map of the
+    WHOLE bench frame -- make_pair(1080, 1920, 192, seed=1), the frame the timed region runs -- against the map the
+    unmodified reference computed for it (tests/golden/full_cases.npz F3p, or F3c with --consistent; generated once in the
+    build container by tests/golden/make_golden_full.py), all 2 073 600 pixels, no tie exclusion.  `cases` keeps the
+    full-width 72-row strips of rounds 2-4 (wide_cases W3a / W3b), the GSW frame of config 4 (F4, bit-exact bar) and a
+    real photograph (photo_cases P2a).  0 s of CPU time.  With world > 1 every ASW case goes through a StripContext over
+    all ranks (row strips + RCCL halo exchange + all-gather, the path the timed region ran) -- every rank must call
+    this; rank 0 gets the figures."""
     import numpy as np
     import torch
     import simplestereo_amd as ss
@@ -370,12 +436,27 @@ def bad1_on_reference_strips(dev, rank=0, world=1):
     pmaps = np.load(os.path.join(gdir, "photo_cases.npz"))
     pmeta = json.load(open(os.path.join(gdir, "photo_cases.json")))
     ppairs = np.load(os.path.join(gdir, "photo_pairs.npz"))
-    cases, bad, exact, pix = {}, 0, 0, 0
-    for cid in ("W3a", "W3b", "P2a"):
-        if cid.startswith("W"):
+    fmaps, fmeta = None, {}
+    if os.path.exists(os.path.join(gdir, "full_cases.npz")):
+        fmaps = np.load(os.path.join(gdir, "full_cases.npz"))
+        fmeta = json.load(open(os.path.join(gdir, "full_cases.json")))
+    head = "F3c" if consistent else "F3p"
+    order = [c for c in (head, "F3c" if head == "F3p" else "F3p", "F4") if fmaps is not None and c in fmaps.files] + ["W3a", "W3b", "P2a"]
+    cases, frames = {}, {}
+    for cid in order:
+        if cid.startswith("F"):
+            m = fmeta[cid]
+            key = tuple(m["frame"])
+            if key not in frames:
+                frames[key] = make_pair(*key)[:2]
+            a, b = frames[key]
+            want, what = fmaps[cid], m["recipe"]
+        elif cid.startswith("W"):
             m = meta[cid]
-            H, W, maxD, seed = m["frame"]
-            L, R, _ = make_pair(H, W, maxD, seed)
+            key = tuple(m["frame"])
+            if key not in frames:
+                frames[key] = make_pair(*key)[:2]
+            L, R = frames[key]
             a = np.ascontiguousarray(L[m["row0"]:m["row0"] + m["rows"]])
             b = np.ascontiguousarray(R[m["row0"]:m["row0"] + m["rows"]])
             want, what = maps[cid], m["recipe"]
@@ -384,8 +465,9 @@ def bad1_on_reference_strips(dev, rank=0, world=1):
             a, b = np.ascontiguousarray(ppairs[m["pair"] + "_L"]), np.ascontiguousarray(ppairs[m["pair"] + "_R"])
             want, what = pmaps[cid], "photograph: tests/golden/photo_pairs.npz %s (reference examples/res/2 lawn pair, rectified, native width)" % m["pair"]
         p = {k: v for k, v in m["params"].items() if k != "algo"}
-        matcher = ss.passive.StereoASW(**p)
-        if world > 1:
+        gsw = m["params"]["algo"] == "gsw"
+        matcher = ss.passive.StereoGSW(**p) if gsw else ss.passive.StereoASW(**p)
+        if world > 1 and not gsw:
             rows = a.shape[0]
             q0, q1 = strips.strip_bounds(rows, world, rank)
             ctx = strips.StripContext(matcher, rows, a.shape[1], rank, world, dev)
@@ -395,16 +477,25 @@ def bad1_on_reference_strips(dev, rank=0, world=1):
             d = matcher.compute(a, b)
         diff = np.abs(d.astype(np.int32) - want.astype(np.int32))
         cases[cid] = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
-                      "pixels": int(diff.size), "consistent": bool(p["consistent"]), "maxDisparity": p["maxDisparity"],
+                      "pixels": int(diff.size), "bad1_pixels": int(np.count_nonzero(diff > 1)),
+                      "differing_pixels": int(np.count_nonzero(diff)), "matcher": "GSW" if gsw else "ASW",
+                      "consistent": bool(p.get("consistent", True if gsw else False)), "maxDisparity": p["maxDisparity"],
                       "minDisparity": p["minDisparity"], "recipe": what}
-        if cid.startswith("W"):          # the headline figure stays the config-3 geometry; the photograph is reported next to it
-            bad += int(np.count_nonzero(diff > 1)); exact += int(np.count_nonzero(diff == 0)); pix += int(diff.size)
-    return {"percent": 100.0 * bad / pix, "exact_percent": 100.0 * exact / pix, "pixels": pix, "cases": cases,
-            "through": "one launch per case" if world == 1 else "StripContext over %d ranks (row strips, RCCL halo exchange, all_gather)" % world,
-            "source": "tests/golden/wide_cases.npz W3a + W3b: full-width 1920 x 72 strips of the config-3 frames (seed 0 plain, "
-                      "seed 1 = this run's frame with consistent=True), D 0..192, win 35, maps by the unmodified reference "
-                      "(_passive.cpp via oracle/_ref, tests/golden/make_golden_wide.py); cases.P2a: a real photograph "
-                      "(tests/golden/make_golden_photo.py), not part of `percent`"}
+    through = "one launch per case" if world == 1 else "StripContext over %d ranks (row strips, RCCL halo exchange, all_gather)" % world
+    if head in cases:
+        h = cases[head]
+        return {"percent": h["percent"], "exact_percent": h["exact_percent"], "pixels": h["pixels"], "bad1_pixels": h["bad1_pixels"],
+                "differing_pixels": h["differing_pixels"], "headline_case": head, "tie_exclusion": "none", "cases": cases, "through": through,
+                "source": "tests/golden/full_cases.npz %s: the WHOLE frame of this run (make_pair(1080,1920,192,seed=1), D 0..192, win 35, "
+                          "consistent=%s) through the unmodified reference (_passive.cpp via oracle/_ref, "
+                          "tests/golden/make_golden_full.py), every pixel counted; cases: the other full-frame maps (F3c/F3p, "
+                          "F4 = GSW config 4), the 72-row strips W3a / W3b of earlier rounds and a photograph (P2a)" % (head, consistent)}
+    # (no full-frame golden in the tree: the strips of rounds 2-4)
+    bad = sum(int(round(c["percent"] * c["pixels"] / 100.0)) for k, c in cases.items() if k.startswith("W"))
+    pix = sum(c["pixels"] for k, c in cases.items() if k.startswith("W"))
+    exact = sum(c["exact_percent"] * c["pixels"] / 100.0 for k, c in cases.items() if k.startswith("W"))
+    return {"percent": 100.0 * bad / pix, "exact_percent": 100.0 * exact / pix, "pixels": pix, "cases": cases, "through": through,
+            "source": "tests/golden/wide_cases.npz W3a + W3b: full-width 1920 x 72 strips of the config-3 frames (full_cases.npz absent)"}
 
 
 def e2e_host_arrays(seed, resident_ms):
@@ -519,7 +610,10 @@ def main():
                     help="cpu_baseline sample height in rows per host thread (the reference schedules one row per job)")
     ap.add_argument("--cpu-crop-cols", type=int, default=512,
                     help="cpu_baseline sample width (centre columns); 0 = full width (minutes of CPU time at 1080p)")
-    ap.add_argument("--cpu-repeats", type=int, default=2, help="how many times the cpu_baseline sample of the reference is timed")
+    ap.add_argument("--cpu-repeats", type=int, default=2, help="how many times the (pinned) cpu_baseline sample of the reference is timed")
+    ap.add_argument("--cpu-pin-cores", type=int, default=32,
+                    help="cpu_baseline headline: pin the reference to this many CPUs on distinct physical cores (min with the affinity mask)")
+    ap.add_argument("--cpu-pinned-rows-per-core", type=int, default=4, help="row jobs per pinned core in the headline cpu_baseline sample")
     ap.add_argument("--with-alternate", action="store_true",
                     help="also time the opt-in alternate-rows mode after the timed region (extra JSON key)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-array (PCIe-inclusive) timings")
@@ -663,7 +757,7 @@ def main():
     if world > 1 and not args.no_bad1:
         # the accuracy half of the metric THROUGH the distributed path (every rank takes part; rank 0 keeps the figures)
         try:
-            bad1_dist = bad1_on_reference_strips(dev, rank, world)
+            bad1_dist = bad1_on_reference_strips(dev, rank, world, consistent=args.consistent)
         except Exception as e:      # noqa: BLE001
             bad1_dist = {"percent": None, "source": repr(e)[:200]}
 
@@ -756,7 +850,7 @@ def main():
                 line["pointwise_kernels"] = {"error": repr(e)[:200]}
         if world == 1 and not use_dist and not args.no_bad1:
             try:
-                line["bad1_vs_cpu_ref"] = bad1_on_reference_strips(dev)
+                line["bad1_vs_cpu_ref"] = bad1_on_reference_strips(dev, consistent=args.consistent)
             except Exception as e:      # noqa: BLE001
                 line["bad1_vs_cpu_ref"] = {"percent": None, "source": repr(e)[:200]}
         if world == 1 and not use_dist and not args.no_e2e:
@@ -769,7 +863,8 @@ def main():
             except Exception as e:      # noqa: BLE001
                 line["e2e_host_arrays"] = {"error": repr(e)[:200]}
         if world == 1 and not use_dist and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1], repeats=args.cpu_repeats)
+            cb = cpu_baseline(cfg, args.seed, args.cpu_rows_per_thread, crop_cols=args.cpu_crop_cols or cfg[1], repeats=args.cpu_repeats,
+                              pin_cores=args.cpu_pin_cores, pinned_rows_per_core=args.cpu_pinned_rows_per_core)
             # second half of BASELINE's metric: % bad-1.0 of the GPU map vs the CPU reference map, on the strip
             # the CPU baseline computed (matched as a stand-alone sub-image by both)
             try:
@@ -814,6 +909,15 @@ def main():
             if cb["value"]:
                 line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
                 line["speedup_vs_cpu_baseline_range"] = [line["value"] / cb["value_max"], line["value"] / cb["value_min"]]
+                line["speedup_vs_cpu_baseline_cores"] = cb["cores"]
+                # GPU against ONE busy host core (effective cores = process CPU seconds / wall seconds of the sample):
+                # divide by a core count to get the ratio against that many cores (north_star's 2000 x holds up to
+                # speedup_per_effective_core / 2000 cores of this host)
+                if cb.get("value_per_effective_core"):
+                    line["speedup_per_effective_core"] = line["value"] / cb["value_per_effective_core"]
+                    line["cores_at_which_speedup_is_2000x"] = line["speedup_per_effective_core"] / 2000.0
+                if cb.get("all_threads", {}).get("value"):
+                    line["speedup_vs_cpu_all_host_threads"] = line["value"] / cb["all_threads"]["value"]
                 if cb.get("hoisted", {}).get("value"):
                     line["speedup_vs_cpu_hoisted_port"] = line["value"] / cb["hoisted"]["value"]
         result = json.dumps(line)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSAMD_ABI_VERSION 3      /* 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
+#define SSAMD_ABI_VERSION 4      /* 4: ssamd_asw_exact* (round 5); 3: GSW autotuning; 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
 
 #define SSAMD_OK 0
 #define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
@@ -104,6 +104,26 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int winSize, int maxDisparity, int minDisparity,
                      int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream);
+
+/* ---- ASW with the reference's fp64 argmin on near-ties ("exact" mode, opt-in) -----
+ * The reference aggregates in double (_passive.cpp:23, 56-95); ssamd_asw* accumulate in fp32 and may pick the other one of
+ * two candidates whose costs agree to ~1e-6 relative (a fraction of a percent of the pixels at worst).  These entry points
+ * run the same kernels, then re-evaluate every candidate whose fp32 cost image is within 128 ulps (1.5e-5 relative) of its
+ * pixel's winner in fp64 -- the reference's expression and summation order (_passive.cpp:37-50, 57-88), fp64 CIELab
+ * (colorconversion.hpp:67-69), no contraction -- and redo those argmins (first minimum wins, :90-93 / 243-246); both the
+ * left- and the right-referenced pass with `consistent`.  Costs H*W*nD*4 bytes of device scratch (1.6 GB at 1080p / 193
+ * disparities) and a few per cent of time.  Candidates whose fp64 costs are EQUAL to the last ulps (every tap saturated
+ * at the cap 40: costs 40 (1 +- 1e-16)) are where the reference's choice depends on its libm's rounding; there the
+ * smallest index wins, as in ssamd_asw.  Same arguments and buffers as ssamd_asw / ssamd_asw_device. */
+int ssamd_asw_exact(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                    int winSize, int maxDisparity, int minDisparity,
+                    double gammaC, double gammaP, int consistent,
+                    int16_t *disparity, int device);
+int ssamd_asw_exact_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                           int out_row0, int out_rows,
+                           int winSize, int maxDisparity, int minDisparity,
+                           double gammaC, double gammaP, int consistent,
+                           int16_t *d_disparity, void *stream);
 
 /* ---- "alternate pixel" ASW -------------------------------------
  * The faster variant the reference only sketches in a docstring todo (passive.py:43-46: "compute
@@ -210,7 +230,8 @@ int ssamd_debug_gsw_sqrt(int n, float *out);
 #define SSAMD_K_REMAP 5      /* rectification remap (bilinear)                    */
 #define SSAMD_K_REPROJECT 6  /* disparity -> 3-D points                           */
 #define SSAMD_K_ASW_ALT 7    /* alternate-rows mode: bounded search on the odd rows */
-#define SSAMD_K_COUNT 8
+#define SSAMD_K_ASW_EXACT 8  /* fp64 tie-break pass of ssamd_asw_exact*                */
+#define SSAMD_K_COUNT 9
 int ssamd_profile_enable(int on);
 int ssamd_profile_reset(void);
 int ssamd_profile_read(double *ms /*[SSAMD_K_COUNT]*/, long long *launches /*[SSAMD_K_COUNT]*/);
@@ -227,7 +248,10 @@ int ssamd_set_option(const char *name, const char *value);
  * production).  "evol_fallbacks": ASW calls that could not get the pre-computed TAD volume (device memory short) and
  * ran the phase-shifted kernel with in-kernel e tiles, or a workgroup kernel instead of the small-range wave kernel;
  * "evol_bytes": capacity of the volume buffer the context holds right now; "tail_splits": phase-shifted launches whose last
- * partial round of workgroups ran as half-width tiles.  SSAMD_EINVAL for an unknown name. */
+ * partial round of workgroups ran as half-width tiles; "exact_calls": ssamd_asw_exact* calls; of the LAST such call (these
+ * synchronise the device): "exact_entries" candidates re-evaluated in fp64, "exact_flagged_left" / "exact_flagged_right"
+ * pixels with near-ties, "exact_overflow" 1 when the candidate queue overflowed (the fp32 map was kept).
+ * SSAMD_EINVAL for an unknown name. */
 int ssamd_counter(int device, const char *name, long long *value);
 
 /* Autotuning of the ASW launch geometry.  When it applies, the first ssamd_asw* call for a problem shape (width,

@@ -393,6 +393,9 @@ class RectifiedStereoRig(StereoRig):
         R2 = self.Rcommon.dot(self.R.T)
         self.mapx1, self.mapy1 = _init_undistort_rectify_map(self.intrinsic1, self.distCoeffs1, R1, self.K1, destDims)
         self.mapx2, self.mapy2 = _init_undistort_rectify_map(self.intrinsic2, self.distCoeffs2, R2, self.K2, destDims)
+        # device copies of the previous maps are stale (a new array may reuse a freed address) and would stay resident in HBM
+        self.__dict__["_maps_gen"] = self.__dict__.get("_maps_gen", 0) + 1
+        self.__dict__.pop("_dev_maps", None)
 
     def rectifyImages(self, img1, img2, interpolation=INTER_LINEAR):
         """
@@ -413,7 +416,7 @@ class RectifiedStereoRig(StereoRig):
         """float32 maps of camera `which` (1 / 2) as tensors on `device`, uploaded once per rig, device and map array"""
         import torch
         mx, my = (self.mapx1, self.mapy1) if which == 1 else (self.mapx2, self.mapy2)
-        key = (which, str(device), mx.ctypes.data, mx.shape)
+        key = (which, str(device), self.__dict__.get("_maps_gen", 0), mx.ctypes.data, mx.shape)
         cache = self.__dict__.setdefault("_dev_maps", {})
         if key not in cache:                      # maps change only through computeRectificationMaps
             cache[key] = (torch.from_numpy(np.ascontiguousarray(mx)).to(device),

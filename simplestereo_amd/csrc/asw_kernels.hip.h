@@ -73,6 +73,8 @@ struct AswArgs {
                                  //   e tiles are built in the kernel), [disparity chunk][image row - erow0][evolW columns][g.Se bytes]
     int erow0, erows, evolW;
     float *costs;                // optional [rows][W][nD] raw cost dump
+    int cost_keys;               // 1: the dump holds the 32-bit cost images of asw_cost_key (bit patterns) instead of the costs: the
+                                 //    fp64 tie-break pass compares them with the winning keys (asw_exact_kernels.hip.h)
     int H, W, win, pad, minD, maxD, row0, rows;
     int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)
     float kC;                    // -log2(e)/gammaC
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
-                        A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                        A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = A.cost_keys ? __uint_as_float((uint32_t)(hi >> 32)) : c;
                 }
             }
             if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);

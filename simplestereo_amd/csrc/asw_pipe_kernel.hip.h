@@ -517,7 +517,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
-                        A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                        A.costs[((size_t)(y - A.row0) * W + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = A.cost_keys ? __uint_as_float((uint32_t)(hi >> 32)) : c;
                 }
             }
             if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);

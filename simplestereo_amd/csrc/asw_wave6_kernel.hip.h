@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + RD - 1] = min(diag[xi - di + RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
-                        A.costs[(orow + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                        A.costs[(orow + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = A.cost_keys ? __uint_as_float((uint32_t)(hi >> 32)) : c;
                 }
             }
             if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);

@@ -43,6 +43,7 @@ struct AswWaveArgs {
     u64 *keyL, *keyR;
     int16_t *disp;               // non-null: no right-referenced pass -> the wave writes the disparities itself
     float *costs;                // optional raw cost dump
+    int cost_keys;               // 1: cost images instead of costs (AswArgs::cost_keys)
     const unsigned char *evol;   // TAD volume (required)
     int erow0, erows, evolW;
     int H, W, win, pad, minD, maxD, row0, rows, ystep;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
-                        A.costs[(orow + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = c;
+                        A.costs[(orow + x) * (A.maxD - A.minD + 1) + (d - A.minD)] = A.cost_keys ? __uint_as_float((uint32_t)(hi >> 32)) : c;
                 }
             }
             if (bl != KEY_NONE) atomicMin(&bestL[RX * xg + xi], bl);

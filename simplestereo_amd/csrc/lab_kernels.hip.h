@@ -43,7 +43,9 @@ __device__ __forceinline__ double lab_f(double t)
     return (7.787 * t) + (16.0 / 116.0);
 }
 
-__device__ __forceinline__ void bgr_to_lab(uint32_t B, uint32_t G, uint32_t R, float &L, float &a, float &b)
+// The reference's Lab values are DOUBLES (colorconversion.hpp:67-69: 116 * y - 16 ... on doubles that hold float powf results);
+// the aggregation kernels use them rounded to float, the fp64 tie-break pass (asw_exact_kernels.hip.h) as they are.
+__device__ __forceinline__ void bgr_to_lab_f64(uint32_t B, uint32_t G, uint32_t R, double &L, double &a, double &b)
 {
     const float r = c_lin100[R], g = c_lin100[G], bl = c_lin100[B];
     // observer 2 deg / D65 matrix in fp64 (colorconversion.hpp:40-42)
@@ -52,9 +54,18 @@ __device__ __forceinline__ void bgr_to_lab(uint32_t B, uint32_t G, uint32_t R, f
     const double Z = r * 0.0193 + g * 0.1192 + bl * 0.9505;
     const float refX = 95.047f, refY = 100.0f, refZ = 108.883f;   // float constants, :48
     const double fx = lab_f(X / refX), fy = lab_f(Y / refY), fz = lab_f(Z / refZ);
-    L = (float)(116 * fy - 16);
-    a = (float)(500 * (fx - fy));
-    b = (float)(200 * (fy - fz));
+    L = 116 * fy - 16;
+    a = 500 * (fx - fy);
+    b = 200 * (fy - fz);
+}
+
+__device__ __forceinline__ void bgr_to_lab(uint32_t B, uint32_t G, uint32_t R, float &L, float &a, float &b)
+{
+    double L64, a64, b64;
+    bgr_to_lab_f64(B, G, R, L64, a64, b64);
+    L = (float)L64;
+    a = (float)a64;
+    b = (float)b64;
 }
 
 // One thread per pixel; 4 consecutive pixels share 12 contiguous bytes but a 3-byte-per-lane read is still fully

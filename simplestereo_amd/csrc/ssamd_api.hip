@@ -26,6 +26,7 @@
 #include "asw_alt_kernels.hip.h"
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
+#include "asw_exact_kernels.hip.h"
 #include "rig_kernels.hip.h"
 
 using namespace ssamd;
@@ -72,6 +73,8 @@ struct Tuning {
     int lds_relax = 1;                // 0: a phase-shifted tile must fit LDS with its staged colour bytes even when the TAD volume makes them unnecessary
     int wave_creg = 1;                // 0: the wave kernel keeps its window centres in LDS (round-3 form)
     int asw_tail = -1;                // -1: the host decides; 0: never split the last partial round of workgroups into half-width tiles; 1: whenever possible
+    int exact_tol = 128;              // fp64 tie-break pass: candidates within this many ulps of the winning cost image are re-evaluated
+    int exact_cap = 0;                // 0 unset: queue capacity of the tie-break pass in entries (test hook: a tiny queue overflows)
 };
 std::mutex g_tune_mutex;
 std::atomic<unsigned> g_tune_version{1};
@@ -101,6 +104,8 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_TAIL") t.asw_tail = num(-1);
     else if (name == "SSAMD_ASW_WAVE_CREG") t.wave_creg = num(1);
     else if (name == "SSAMD_ASW_LDS_RELAX") t.lds_relax = num(1);
+    else if (name == "SSAMD_EXACT_TOL") t.exact_tol = v ? std::max(0, atoi(v)) : 128;
+    else if (name == "SSAMD_EXACT_CAP") t.exact_cap = v ? std::max(1, atoi(v)) : 0;
     else return false;
     return true;
 }
@@ -108,7 +113,8 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
 const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_ASW_PIPE", "SSAMD_ASW_DEPHASE", "SSAMD_ASW_EVOL",
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
-                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG", "SSAMD_ASW_LDS_RELAX"};
+                                    "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG", "SSAMD_ASW_LDS_RELAX",
+                                    "SSAMD_EXACT_TOL", "SSAMD_EXACT_CAP"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -206,6 +212,7 @@ struct TableEntry {
     int k0 = 0; double k1 = 0;
     DevBuf dev;
     std::vector<float> host;
+    std::vector<double> host64;          // (the fp64 proximity table of the tie-break pass)
 };
 struct TableCache {
     std::list<TableEntry> entries;       // most recently used first
@@ -225,15 +232,19 @@ struct TableCache {
 struct Ctx {
     std::mutex mu;                      // serialises the calls on this device
     int dev = -1;
+    int cus = 256;                      // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
     DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol, altdisp;
-    TableCache proxTabs{8}, gswTabs{4};
+    DevBuf xlabL, xlabR, xflags, xqueue, xcost, xslots, xctr;      // fp64 tie-break pass (asw_exact_kernels.hip.h)
+    unsigned int xcap = 0;              // queue capacity of the last exact call
+    TableCache proxTabs{8}, gswTabs{4}, proxTabs64{8};
     std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
     int evol_small_calls = 0;           // consecutive calls that needed less than a quarter of the TAD volume's capacity
     long long evol_fallbacks = 0;       // calls that ran without the volume (in-kernel e tiles) or off the wave kernel for lack of memory
     long long tail_splits = 0;          // phase-shifted launches whose last partial round of workgroups ran as half-width tiles
+    long long exact_calls = 0;          // ASW calls that ran the fp64 tie-break pass
     Profile prof;
 };
 
@@ -288,6 +299,9 @@ int get_ctx(int device, CtxLock &out)
     out.c = &c;
     if (c.dev < 0) {
         c.dev = device;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c.cus = cus;
+        else (void)hipGetLastError();
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c.scratch_free, hipEventDisableTiming));
     }
@@ -856,6 +870,95 @@ int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
     return SSAMD_OK;
 }
 
+// The same table in fp64, by the HOST's libm -- the reference builds it with the same expression and the same library
+// (_passive.cpp:360-364: exp(-sqrt(pow(i-padding,2) + pow(j-padding,2))/gammaP)) -- for the fp64 tie-break pass.
+int get_prox64(Ctx &c, int win, double gammaP, hipStream_t s, const double **out)
+{
+    if (TableEntry *e = c.proxTabs64.find(win, gammaP)) { *out = (const double *)e->dev.ptr; return SSAMD_OK; }
+    if (c.proxTabs64.entries.size() >= c.proxTabs64.max_entries) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(c.proxTabs64.entries.back().dev.ptr);
+        c.proxTabs64.entries.pop_back();
+    }
+    c.proxTabs64.entries.emplace_front();
+    TableEntry &e = c.proxTabs64.entries.front();
+    e.k0 = win; e.k1 = gammaP;
+    const int p = win / 2;
+    e.host64.resize((size_t)win * win);
+    for (int i = 0; i < win; ++i)
+        for (int j = 0; j < win; ++j)
+            e.host64[(size_t)i * win + j] = std::exp(-std::sqrt(std::pow(i - p, 2) + std::pow(j - p, 2)) / gammaP);
+    int rc = e.dev.reserve(e.host64.size() * 8);
+    if (rc) { c.proxTabs64.entries.pop_front(); return rc; }
+    hipError_t he = hipMemcpyAsync(e.dev.ptr, e.host64.data(), e.host64.size() * 8, hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) {
+        (void)hipFree(e.dev.ptr);
+        c.proxTabs64.entries.pop_front();
+        return fail(SSAMD_EHIP, "hipMemcpyAsync(fp64 proximity table) failed: %s", hipGetErrorString(he));
+    }
+    *out = (const double *)e.dev.ptr;
+    return SSAMD_OK;
+}
+
+// fp64 tie-break pass (asw_exact_kernels.hip.h) between the aggregation and the finalisation of an ASW call: c.costs holds the
+// cost images of every candidate, c.keyL / c.keyR the fp32 winners.  Rewrites the low words of the keys of pixels whose
+// near-ties fp64 decides differently.
+int asw_exact_pass(Ctx &c, int H, int W, int row0, int rows, int win, int maxD, int minD, double gammaC, double gammaP,
+                   bool consistent, hipStream_t s)
+{
+    const int nD = maxD - minD + 1, p = win / 2;
+    const size_t nout = (size_t)rows * W, npix = (size_t)H * W;
+    if (nout >= ((size_t)1 << 32)) return fail(SSAMD_ELIMIT, "exact mode: more than 2^32 output pixels per call");
+    int rc;
+    const double *d_prox = nullptr;
+    if ((rc = get_prox64(c, win, gammaP, s, &d_prox))) return rc;
+    if ((rc = c.xlabL.reserve(npix * 24)) || (rc = c.xlabR.reserve(npix * 24))) return rc;
+    // queue: room for a few candidates of every pixel, bounded (a frame of saturated noise can flag every candidate of every
+    // pixel: those entries all evaluate to the same cost and the smallest index wins anyway; an overflow leaves the fp32 map)
+    size_t cap = std::min<size_t>(std::max<size_t>(4 * nout, (size_t)1 << 16), (size_t)1 << 25);
+    if (tune().exact_cap) cap = (size_t)tune().exact_cap;
+    if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(2 * nout)) ||
+        (rc = c.xslots.reserve(nout * 24)) || (rc = c.xctr.reserve(64)))
+        return rc;
+    c.xcap = (unsigned int)cap;
+    HIP_TRY(hipMemsetAsync(c.xflags.ptr, 0, 2 * nout, s));
+    HIP_TRY(hipMemsetAsync(c.xslots.ptr, 0xFF, nout * 24, s));
+    HIP_TRY(hipMemsetAsync(c.xctr.ptr, 0, 64, s));
+    AswExactArgs x;
+    x.recL = (const PixRec *)c.recL.ptr; x.recR = (const PixRec *)c.recR.ptr;
+    x.labL = (const double *)c.xlabL.ptr; x.labR = (const double *)c.xlabR.ptr;
+    x.prox = d_prox;
+    x.kvol = (const uint32_t *)c.costs.ptr;
+    x.keyL = (u64 *)c.keyL.ptr; x.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+    x.flagL = (unsigned char *)c.xflags.ptr; x.flagR = x.flagL + nout;
+    x.entries = (u64 *)c.xqueue.ptr; x.counter = (unsigned int *)c.xctr.ptr; x.cap = (unsigned int)cap;
+    x.ecost = (double *)c.xcost.ptr;
+    x.costL = (u64 *)c.xslots.ptr; x.costR = x.costL + nout;
+    x.idxL = (uint32_t *)(x.costR + nout); x.idxR = x.idxL + nout;
+    x.H = H; x.W = W; x.win = win; x.pad = p; x.minD = minD; x.maxD = maxD; x.row0 = row0; x.rows = rows;
+    x.tol = (uint32_t)tune().exact_tol;
+    x.gammaC = gammaC;
+    Timed t(c, s, SSAMD_K_ASW_EXACT);
+    {
+        const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
+        const long long np2 = (long long)(r1 - r0) * W;
+        const int blocks = (int)std::min<long long>((2 * np2 + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(bgr2lab_f64_pair_kernel, dim3(blocks), dim3(256), 0, s, x.recL + (size_t)r0 * W, x.recR + (size_t)r0 * W,
+                           (double *)c.xlabL.ptr + 3 * (size_t)r0 * W, (double *)c.xlabR.ptr + 3 * (size_t)r0 * W, np2);
+    }
+    const long long per_row = (long long)W * nD;
+    const int fx = (int)std::min<long long>((per_row + 255) / 256, 64);
+    hipLaunchKernelGGL(asw_exact_flag_kernel, dim3(fx, rows), dim3(256), 0, s, x);
+    const int pb = (int)std::min<long long>(((long long)nout + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(asw_exact_winners_kernel, dim3(pb), dim3(256), 0, s, x);
+    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 16), dim3(64), 0, s, x);
+    hipLaunchKernelGGL(asw_exact_resolve_kernel, dim3(256 * 4), dim3(256), 0, s, x);
+    hipLaunchKernelGGL(asw_exact_patch_kernel, dim3(pb), dim3(256), 0, s, x);
+    HIP_TRY(hipGetLastError());
+    ++c.exact_calls;
+    return SSAMD_OK;
+}
+
 int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_disp, hipStream_t s,
                     int16_t *d_raw_right = nullptr)
 {
@@ -885,11 +988,19 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
 // (remap_lab_records_pair_kernel: rectification + Lab in one launch)
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
-                    float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr, const RemapSrc *rm = nullptr)
+                    float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr, const RemapSrc *rm = nullptr,
+                    bool exact = false)
 {
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
+    if (exact && (alternate || d_costs)) return fail(SSAMD_EINVAL, "the exact (fp64 tie-break) mode has no alternate-rows form and no cost dump");
+    if (maxD < minD) exact = false;                                   // empty candidate loops: nothing to break ties between
+    if (exact) {
+        // the aggregation kernels dump the cost image of every candidate into c.costs (their verification dump, keys instead of floats)
+        if ((rc = c.costs.reserve((size_t)rows * W * (size_t)(maxD - minD + 1) * 4))) return rc;
+        d_costs = (float *)c.costs.ptr;
+    }
     // alternate-rows mode: row0 is matched exactly, then every second row; the range must end with an exact row or with
     // the image (asw_alternate_rows arranges that for strips)
     if (alternate && d_costs) return fail(SSAMD_EINVAL, "the alternate-rows mode has no cost dump");
@@ -910,7 +1021,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     std::vector<AswGeom> trial;
     const double call_taps = (double)W * grows * nD * win * win;
     const int tune_mode = g_autotune.load();
-    const bool tune_now = tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS);
+    const bool tune_now = (tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS)) && !exact;   // (trial launches would all dump)
     bool tuned_already;
     { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_asw_geom_tuned.count(shape) != 0; }
     if (tune_now && nD >= 1 && !asw_geometry_forced() && !tuned_already) {
@@ -948,7 +1059,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     if (nD >= 1 && !wave_volume_fits(a.g)) a.g.wave_rx = 0;
     trial.erase(std::remove_if(trial.begin(), trial.end(), [&](const AswGeom &g) { return !wave_volume_fits(g); }), trial.end());
     if (trial.size() < 2) trial.clear();
-    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent; };
+    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent && !exact; };   // (the tie-break pass patches keys)
     bool need_keys = !is_direct(a.g) || alternate;  // the alternate mode merges its odd-row jobs through the left keys
     for (const AswGeom &g : trial) need_keys = need_keys || !is_direct(g);
     if (need_keys) {
@@ -983,6 +1094,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.prox = d_prox;
         a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
         a.costs = d_costs;
+        a.cost_keys = exact ? 1 : 0;
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
         a.ystep = alternate ? 2 : 1;
@@ -1053,7 +1165,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.disp = is_direct(g) ? d_disp : nullptr;
             if (g.wave_rx) {                  // (prepare_evol(g) filled wa.g and built the volume)
                 wa.recL = a.recL; wa.recR = a.recR; wa.prox = a.prox;
-                wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs;
+                wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs; wa.cost_keys = a.cost_keys;
                 wa.evol = a.evol; wa.erow0 = a.erow0; wa.erows = a.erows; wa.evolW = a.evolW;
                 wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
                 wa.ystep = a.ystep; wa.kC = a.kC;
@@ -1111,7 +1223,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 int rows_main = grows;
                 AswGeom tail_g;
                 if (!alternate && tune().asw_tail != 0 && g.XG >= 4) {
-                    const long long per_row = (long long)grid.x * g.nchunks, n = per_row * grows, slots = 256;
+                    // workgroups in flight at a time: the device's CUs x the tile's residency (168 VGPRs -> three waves per SIMD;
+                    // the tile's LDS).  One per CU for the 9- to 12-wave tiles of the headline configurations.
+                    const int per_simd = (g.threads / 64 + 3) / 4;
+                    const long long resident = std::max(1, std::min(3 / std::max(1, per_simd), (160 * 1024) / std::max(1, pipe_lds)));
+                    const long long per_row = (long long)grid.x * g.nchunks, n = per_row * grows, slots = (long long)c.cus * resident;
                     const long long full = n / slots, rem = n - full * slots;
                     if (full >= 1 && rem > 0 && 2 * rem <= slots && (full < 32 || tune().asw_tail > 0)) {
                         const int rm = (int)(full * slots / per_row);
@@ -1164,9 +1280,13 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             // late ones
             std::vector<float> cand_ms(trial.size(), 3.0e38f);
             bool all_prepared = true;     // a candidate whose volume cannot be had right now is never launched, and the verdict of such a round is not cached
+            // (a phase-shifted tile whose volume cannot be had is timed with in-kernel e tiles, or fails its launch when it was
+            //  planned on the volume's LDS saving: that round says nothing about the tile, so its verdict is not kept either)
+            const bool want_evol = tune().asw_evol != 0;
             for (const AswGeom &g : trial) {                                             // code load, clocks, scratch
-                if (prepare_evol(g) == SSAMD_OK) (void)launch(g);
-                else all_prepared = false;
+                if (prepare_evol(g) != SSAMD_OK) { all_prepared = false; continue; }
+                if (g.pipe && !g.wave_rx && want_evol && !a.evol) all_prepared = false;
+                if (launch(g) != SSAMD_OK) all_prepared = false;
             }
             for (int round = 0; round < 4; ++round)
                 for (size_t ci = 0; ci < trial.size(); ++ci) {
@@ -1174,6 +1294,9 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                     if (hipEventRecord(e0, s) == hipSuccess && prepare_evol(trial[ci]) == SSAMD_OK && launch(trial[ci]) == SSAMD_OK &&
                         hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
                         (void)hipEventElapsedTime(&ms, e0, e1);
+                    else
+                        all_prepared = false;
+                    if (trial[ci].pipe && !trial[ci].wave_rx && want_evol && !a.evol) all_prepared = false;
                     if (round > 0) cand_ms[ci] = std::min(cand_ms[ci], ms);  // round 0 is warm-up
                 }
             AswGeom fastest = a.g;
@@ -1194,7 +1317,23 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         }
         {
             AswGeom final_geom = a.g;
-            if ((rc = prepare_evol(final_geom))) return rc;
+            rc = prepare_evol(final_geom);
+            if (rc == SSAMD_ENOMEM && final_geom.wave_rx) {
+                // the volume's hipMalloc failed although the pre-check said it fits (fragmentation, another allocator on the
+                // same GPU): the wave kernel cannot run without it, the workgroup geometry stored next to it can (in-kernel
+                // e tiles, or a smaller volume if that one can be had)
+                ++c.evol_fallbacks;
+                g_err.clear();
+                final_geom.wave_rx = 0;
+                a.g = final_geom;
+                if (!is_direct(final_geom) && !need_keys) {
+                    if ((rc = c.keyL.reserve(nout * 8))) return rc;
+                    HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+                    need_keys = true;
+                }
+                rc = prepare_evol(final_geom);
+            }
+            if (rc) return rc;
             if (final_geom.pipe && !final_geom.wave_rx && !a.evol && final_geom.lds_bytes > 160 * 1024) {
                 // the tile was planned on the TAD volume (no staged colour bytes in LDS) and the volume cannot be had: plan
                 // again for the in-kernel e tiles (asw_layout_e: t_pipe_full_lds)
@@ -1216,6 +1355,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         }
     }
     const bool direct = is_direct(a.g);
+    if (exact && (rc = asw_exact_pass(c, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent != 0, s))) return rc;
     if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
     if (alternate && rows > 1) {
         // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
@@ -1511,16 +1651,31 @@ int gsw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 if (trial.size() >= 2) {
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     HIP_TRY(hipEventCreate(&e0));
-                    HIP_TRY(hipEventCreate(&e1));
-                    std::vector<float> cand_ms(trial.size(), 3.0e38f);
-                    for (int round = 0; round < 3; ++round)
+                    if (hipEventCreate(&e1) != hipSuccess) {
+                        (void)hipEventDestroy(e0);
+                        return fail(SSAMD_EHIP, "hipEventCreate failed");
+                    }
+                    std::vector<float> cand_ms(trial.size(), 3.0e38f), warm_ms(trial.size(), 3.0e38f);
+                    std::vector<char> alive(trial.size(), 1);
+                    for (int round = 0; round < 3; ++round) {
                         for (size_t ci = 0; ci < trial.size(); ++ci) {
+                            if (!alive[ci]) continue;
                             float ms = 3.0e38f;
                             if (hipEventRecord(e0, s) == hipSuccess && launch(trial[ci]) == SSAMD_OK && hipEventRecord(e1, s) == hipSuccess &&
                                 hipEventSynchronize(e1) == hipSuccess)
                                 (void)hipEventElapsedTime(&ms, e0, e1);
                             if (round > 0) cand_ms[ci] = std::min(cand_ms[ci], ms);      // round 0 is warm-up
+                            else warm_ms[ci] = ms;
                         }
+                        if (round == 0) {
+                            // a candidate that is twice as slow as the best one in the warm-up round (very narrow tiles can be several
+                            // times slower than the model's choice) is not timed again: bounds what the first call of a shape costs
+                            const float wbest = *std::min_element(warm_ms.begin(), warm_ms.end());
+                            for (size_t ci = 1; ci < trial.size(); ++ci) alive[ci] = warm_ms[ci] <= 2.0f * wbest;
+                        }
+                    }
+                    (void)hipGetLastError();
+                    g_err.clear();            // a failed trial launch is not the call's error
                     GswGeom fastest = trial[0];
                     float best_ms = 3.0e38f;
                     for (size_t ci = 0; ci < trial.size(); ++ci)      // the model's own choice (first) keeps the job unless another is clearly faster
@@ -1560,6 +1715,7 @@ struct HostJob {
     int16_t *disparity;            // full-image output [H][W]
     // ASW
     double gammaC, gammaP; int consistent; float *costs; bool alternate;
+    bool exact;                    // fp64 tie-break pass (ssamd_asw_exact*)
     int16_t *raw_right;            // verification dump (ssamd_asw_argmins): raw right-referenced matches, full image
     // GSW
     int gamma; float fMax; int iterations;
@@ -1589,7 +1745,7 @@ int asw_host_rows(const HostJob &j, int device)
         rc = asw_device_impl(*c, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr, in1 - in0, j.W, j.o0 - in0, rows,
                              j.win, j.maxD, j.minD, j.gammaC, j.gammaP, j.consistent, (int16_t *)c->disp.ptr,
                              j.costs ? (float *)c->costs.ptr : nullptr, s, false,
-                             j.raw_right ? (int16_t *)c->lab.ptr : nullptr);
+                             j.raw_right ? (int16_t *)c->lab.ptr : nullptr, nullptr, j.exact);
     if (rc) return rc;
     if (j.raw_right)
         HIP_TRY(hipMemcpyAsync(j.raw_right + (size_t)j.o0 * j.W, c->lab.ptr, nout * 2, hipMemcpyDeviceToHost, s));
@@ -1701,7 +1857,7 @@ const char *ssamd_kernel_name(int slot)
     static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_pair_kernel + asw_tad_volume_kernel", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
                                                "asw finalize (wta_decode / lr_check_fill)",
                                                "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
-                                               "asw_alt_fill_kernel"};
+                                               "asw_alt_fill_kernel", "asw fp64 tie-break pass (asw_exact_* kernels)"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
 }
 
@@ -1734,6 +1890,16 @@ int ssamd_counter(int device, const char *name, long long *value)
     if (n == "evol_fallbacks") *value = c->evol_fallbacks;
     else if (n == "evol_bytes") *value = (long long)c->evol.cap;
     else if (n == "tail_splits") *value = c->tail_splits;
+    else if (n == "exact_calls") *value = c->exact_calls;
+    else if (n == "exact_entries" || n == "exact_flagged_left" || n == "exact_flagged_right" || n == "exact_overflow") {
+        // of the LAST exact call on this device: candidates re-evaluated in fp64, pixels with near-ties, whether the queue overflowed
+        unsigned int ctr[3] = {0, 0, 0};
+        if (c->xctr.ptr) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(ctr, c->xctr.ptr, sizeof(ctr), hipMemcpyDeviceToHost));
+        }
+        *value = n == "exact_entries" ? ctr[0] : n == "exact_flagged_left" ? ctr[1] : n == "exact_flagged_right" ? ctr[2] : (ctr[0] > c->xcap ? 1 : 0);
+    }
     else return fail(SSAMD_EINVAL, "unknown counter %s", name);
     return SSAMD_OK;
 }
@@ -1801,6 +1967,27 @@ int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream);
+}
+
+int ssamd_asw_exact_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                           int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP, int consistent,
+                           int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
+                           gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream, false, nullptr, nullptr, true);
+}
+
+int ssamd_asw_exact(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                    int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    HostJob j = asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent, disparity, nullptr, false);
+    j.exact = true;
+    return asw_host_rows(j, device);
 }
 
 int ssamd_asw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,

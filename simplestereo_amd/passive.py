@@ -123,12 +123,13 @@ def _device_list(devices):
 
 
 def set_autotune(on=True):
-    """Extension: launch-geometry autotuning of ``StereoASW``.  ``True``: the first ``compute`` call of every
-    problem shape times its candidate geometries on the GPU (up to ~50 extra kernel launches, once) instead of
-    trusting the cost model; ``False``: never; ``None``: the default -- only for small calls (at most 6e10 window
-    taps, i.e. a few milliseconds of kernel time), where that costs at most ~0.4 s once.  Maps are unaffected:
-    every geometry accumulates the same taps in the same order.  Returns the previous mode (True / False / None).
-    The environment variable ``SSAMD_AUTOTUNE=1 / 0 / -1`` sets the initial mode."""
+    """Extension: launch-geometry autotuning of ``StereoASW`` and ``StereoGSW``.  ``True``: the first ``compute`` call of
+    every problem shape times its candidate geometries on the GPU (ASW: up to ~50 extra kernel launches, once; GSW: up to
+    36 candidate strips, one warm-up launch each -- those twice as slow as the best are dropped there -- and two timed
+    rounds of the rest) instead of trusting the cost model; ``False``: never; ``None``: the default -- only for small calls
+    (at most 6e10 window taps, i.e. a few milliseconds of kernel time), where that costs at most ~0.4 s once.  Maps are
+    unaffected: every geometry accumulates the same taps in the same order.  Returns the previous mode (True / False /
+    None).  The environment variable ``SSAMD_AUTOTUNE=1 / 0 / -1`` sets the initial mode."""
     before = _native.lib().ssamd_autotune(-1 if on is None else (1 if on else 0))
     return None if before < 0 else bool(before)
 
@@ -170,14 +171,22 @@ class StereoASW():
         not agree, and fill each invalid run with the smaller of its two valid neighbours
         (default False).  On the GPU this costs one extra reduction, not a second aggregation,
         because the aggregated cost is symmetric in the (left pixel, right pixel) pair.
+    exact : bool
+        Extension (default False): after the fp32 aggregation, every candidate whose cost is within 1.5e-5 relative of
+        its pixel's winner is re-evaluated in fp64 with the reference's own expression and summation order
+        (reference ``_passive.cpp:37-50, 57-88``) and those argmins are redone -- the map is then the reference's
+        wherever double precision can tell the candidates apart (``ssamd_asw_exact*``, include/ssamd.h).  Costs
+        ``H * W * nDisparities * 4`` bytes of device scratch and a few per cent of time.  Not with ``alternate`` or
+        ``devices=[...]``.
     """
 
     def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
-                 device=None, alternate=False):
+                 device=None, alternate=False, exact=False):
         if not (winSize > 0 and winSize % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
         self.device = device
         self.alternate = alternate
+        self.exact = exact
         self.winSize = winSize
         self.maxDisparity = maxDisparity
         self.minDisparity = minDisparity
@@ -194,6 +203,12 @@ class StereoASW():
 
     def _alternate(self, cons):
         return bool(getattr(self, "alternate", False))
+
+    def _exact(self):
+        ex = bool(getattr(self, "exact", False))
+        if ex and bool(getattr(self, "alternate", False)):
+            raise ValueError("exact=True is not available with alternate=True")
+        return ex
 
     def compute(self, img1, img2, devices=None, rectify=None, interpolation=1):
         """
@@ -212,6 +227,10 @@ class StereoASW():
         if rectify is not None:
             if not (_is_device_tensor(img1) and _is_device_tensor(img2)) or devices is not None:
                 raise ValueError("rectify=rig applies to two device tensors (raw frames resident in HBM)")
+            if tuple(img1.shape) != tuple(img2.shape):
+                # cameras of different resolutions (res1 != res2, which rectifyImages supports): the fused launch takes one
+                # source size for both frames, so such rigs go through the two calls it otherwise replaces -- same map
+                return self.compute(*rectify.rectifyImages(img1, img2, interpolation))
             return self._compute_rectified_device(rectify, img1, img2, interpolation)
         if _is_device_tensor(img1) and _is_device_tensor(img2):
             if devices is not None:
@@ -229,6 +248,8 @@ class StereoASW():
         out = np.empty((H, W), np.int16)
         try:
             if devices is not None:
+                if self._exact():
+                    raise ValueError("exact=True is not available with devices=[...] (use row strips of device tensors: strips.py)")
                 arr, n = _device_list(devices)
                 multi = lib.ssamd_asw_alternate_multi if self._alternate(cons) else lib.ssamd_asw_multi
                 _native.check(multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons, out.ctypes.data, arr, n))
@@ -237,8 +258,8 @@ class StereoASW():
                 _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
                                                       out.ctypes.data, dev))
                 return out
-            _native.check(lib.ssamd_asw(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
-                                        out.ctypes.data, dev))
+            op = lib.ssamd_asw_exact if self._exact() else lib.ssamd_asw
+            _native.check(op(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons, out.ctypes.data, dev))
         except _native.NativeError as e:
             _raise_native(e)
         return out
@@ -250,6 +271,8 @@ class StereoASW():
         win, maxd, mind, gc, gp, cons = self._params()
         if self._alternate(cons):
             raise ValueError("rectify=rig is not available with alternate=True")
+        if self._exact():
+            raise ValueError("rectify=rig is not available with exact=True (rectify first: rig.rectifyImages)")
         a, b = _check_pair_tensors(raw1, raw2)
         if not (win > 0 and win % 2 == 1):
             raise ValueError("winSize must be a positive odd number!")
@@ -297,9 +320,9 @@ class StereoASW():
                                                                       int(row_parity) & 1, win, maxd, mind, gc, gp, cons,
                                                                       out.data_ptr(), ctypes.c_void_p(stream)))
                     return out
-                _native.check(lib.ssamd_asw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
-                                                   maxd, mind, gc, gp, cons, out.data_ptr(),
-                                                   ctypes.c_void_p(stream)))
+                op = lib.ssamd_asw_exact_device if self._exact() else lib.ssamd_asw_device
+                _native.check(op(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win, maxd, mind, gc, gp, cons, out.data_ptr(),
+                                 ctypes.c_void_p(stream)))
             except _native.NativeError as e:
                 _raise_native(e)
         return out
@@ -357,6 +380,10 @@ class StereoGSW():
         if rectify is not None:
             if not (_is_device_tensor(img1) and _is_device_tensor(img2)) or devices is not None:
                 raise ValueError("rectify=rig applies to two device tensors (raw frames resident in HBM)")
+            if tuple(img1.shape) != tuple(img2.shape):
+                # cameras of different resolutions (res1 != res2, which rectifyImages supports): the fused launch takes one
+                # source size for both frames, so such rigs go through the two calls it otherwise replaces -- same map
+                return self.compute(*rectify.rectifyImages(img1, img2, interpolation))
             return self._compute_rectified_device(rectify, img1, img2, interpolation)
         if _is_device_tensor(img1) and _is_device_tensor(img2):
             if devices is not None:

@@ -418,19 +418,23 @@ def test_asw_when_the_tad_volume_allocation_really_fails(ss):
         got = m.compute(tL, tR)
         assert torch.equal(got, want)
         assert _native.counter("evol_fallbacks") == n0 + 1
-        # the small-range wave kernel cannot run without its volume: with autotuning off that is a clean error (and no stale
-        # HIP error afterwards); a first call of a shape under the tuner simply ends up on a workgroup candidate
+        # the small-range wave kernel cannot run without its volume: the call falls back to the workgroup geometry stored
+        # next to the wave geometry (round 5; a clean error until round 4) -- same map, the fallback counted, no stale HIP
+        # error afterwards; a first call of a shape under the tuner simply ends up on a workgroup candidate
         small = ss.passive.StereoASW(winSize=35, maxDisparity=16)
         prev = _native.lib().ssamd_autotune(0)
         try:
-            with pytest.raises(_native.NativeError):
-                small.compute(tL, tR)
+            n1 = _native.counter("evol_fallbacks")
+            untuned = small.compute(tL, tR)
+            assert _native.counter("evol_fallbacks") > n1
         finally:
             _native.lib().ssamd_autotune(prev)
         tuned = small.compute(tL, tR)
+        assert torch.equal(untuned, tuned)
+    n2 = _native.counter("evol_fallbacks")
     assert torch.equal(small.compute(tL, tR), tuned)          # same map from the wave kernel once the volume can be had again
     assert torch.equal(m.compute(tL, tR), want)
-    assert _native.counter("evol_fallbacks") == n0 + 1 and _native.counter("evol_bytes") > 0
+    assert _native.counter("evol_fallbacks") == n2 and _native.counter("evol_bytes") > 0
     assert ss.passive.StereoASW(winSize=35, maxDisparity=16).compute(tL, tR).shape == (40, 300)
 
 

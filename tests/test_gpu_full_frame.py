@@ -1,0 +1,63 @@
+"""GPU tier: the WHOLE bench frame against the unmodified reference -- the accuracy half of BASELINE.json's metric
+("% bad-1.0 vs CPU ref") at the headline geometry, on every one of the 2 073 600 pixels.
+
+tests/golden/full_cases.npz holds the maps `_passive.computeASW` / `computeGSW` (reference _passive.cpp:293-400, 703-774,
+compiled where it lies into oracle/_ref) produced for the frame bench.py times, make_pair(1080, 1920, 192, seed=1):
+F3p config 3 (ASW win 35, D 0..192), F3c the same with consistent=True, F4 config 4 (GSW class defaults, D 0..192).
+Generated once in the build container by tests/golden/make_golden_full.py (~1 h on 8 threads).
+
+Bars, with NO tie exclusion of any kind: ASW (fp32 kernels vs the fp64 reference) >= 99.5 % of all pixels within one
+level (north_star) and, tighter, >= 99 % identical; GSW: 0 mismatching pixels."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def full():
+    maps = np.load(os.path.join(G, "full_cases.npz"))
+    meta = json.load(open(os.path.join(G, "full_cases.json")))
+    from simplestereo_amd.synth import make_pair
+    H, W, maxD, seed = next(iter(meta.values()))["frame"]
+    L, R, _ = make_pair(H, W, maxD, seed)
+    return maps, meta, L, R
+
+
+def _stats(d, ref):
+    diff = np.abs(d.astype(np.int32) - ref.astype(np.int32))
+    return diff, float(np.mean(diff <= 1)), float(np.mean(diff == 0))
+
+
+@pytest.mark.parametrize("cid", ["F3p", "F3c"])
+def test_asw_full_bench_frame_vs_reference(cid, full):
+    import simplestereo_amd as ss
+    maps, meta, L, R = full
+    if cid not in maps.files:
+        pytest.skip("%s not generated (tests/golden/make_golden_full.py)" % cid)
+    p = {k: v for k, v in meta[cid]["params"].items() if k != "algo"}
+    d = ss.passive.StereoASW(**p).compute(L, R)
+    ref = maps[cid]
+    assert d.shape == ref.shape == (1080, 1920) and d.dtype == np.int16
+    diff, within1, exact = _stats(d, ref)
+    print("%s full frame, consistent=%s: %d pixels, exact %.5f %%, within-1 %.5f %%, bad-1.0 %.5f %% (%d pixels), differing %d" %
+          (cid, p["consistent"], diff.size, 100 * exact, 100 * within1, 100 * (1 - within1), int(np.count_nonzero(diff > 1)),
+           int(np.count_nonzero(diff))))
+    assert within1 >= 0.995, (cid, within1)
+    assert exact >= 0.99, (cid, exact)
+
+
+def test_gsw_full_bench_frame_vs_reference_bit_exact(full):
+    import simplestereo_amd as ss
+    maps, meta, L, R = full
+    if "F4" not in maps.files:
+        pytest.skip("F4 not generated (tests/golden/make_golden_full.py)")
+    p = {k: v for k, v in meta["F4"]["params"].items() if k != "algo"}
+    d = ss.passive.StereoGSW(**p).compute(L, R)
+    assert d.shape == (1080, 1920)
+    assert np.array_equal(d, maps["F4"]), int(np.count_nonzero(d != maps["F4"]))

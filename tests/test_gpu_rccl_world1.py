@@ -122,7 +122,10 @@ def test_bench_line_of_a_two_rank_run_explains_itself():
     assert line["roofline"]["of_rank"] in (0, 1) and line["roofline"]["kernel_ms"] == rc["kernel_ms_max"]
     assert line["config"]["checksum_equals_single_gpu"] is True and line["config"]["checksum_single_gpu"] == line["config"]["checksum"]
     b = line["bad1_vs_cpu_ref"]
-    assert "StripContext over 2 ranks" in b["through"] and b["percent"] <= 0.5 and set(b["cases"]) == {"W3a", "W3b", "P2a"}
+    assert "StripContext over 2 ranks" in b["through"] and b["percent"] <= 0.5 and {"W3a", "W3b", "P2a"} <= set(b["cases"])
+    # the headline figure is the WHOLE bench frame (tests/golden/full_cases.npz), every pixel counted, through the two strips
+    assert b["headline_case"] == "F3p" and b["pixels"] == 1080 * 1920 and b["tie_exclusion"] == "none"
+    assert b["cases"]["F4"]["differing_pixels"] == 0
     assert b["cases"]["P2a"]["exact_percent"] >= 99.0
 
 
@@ -151,4 +154,12 @@ def test_bench_line_carries_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in line["cpu_baseline"], k
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
-    assert line["bad1_vs_cpu_ref"]["percent"] <= 0.5
+    # the denominator is interpretable: pinned cores, process CPU seconds, effective cores, the per-core rate
+    cb = line["cpu_baseline"]
+    for k in ("host_threads_visible", "affinity_cpus", "pinned_cpus", "cpu_s", "wall_s", "effective_cores", "taps_per_s_per_effective_core",
+              "value_per_effective_core", "all_threads"):
+        assert k in cb, k
+    assert cb["cores"] == len(cb["pinned_cpus"]) <= 32 and 0 < cb["effective_cores"] <= cb["cores"] * 1.05
+    assert line["speedup_per_effective_core"] > line["speedup_vs_cpu_baseline"] > 0
+    b = line["bad1_vs_cpu_ref"]
+    assert b["percent"] <= 0.5 and b["pixels"] == 1080 * 1920 and b["headline_case"] == "F3p" and b["exact_percent"] >= 99.0

@@ -176,3 +176,33 @@ def test_oracle_on_photographs(cid):
     p = {k: v for k, v in m["params"].items() if k != "algo"}
     got = oracle.asw(a, b, hoist=True, **p) if m["params"]["algo"] == "asw" else oracle.gsw(a, b, closed=True, **p)
     assert np.array_equal(got, want)
+
+
+def test_full_frame_golden_rows_reproduced_by_the_restatement():
+    """tests/golden/full_cases.npz (the WHOLE bench frame through the unmodified reference, make_golden_full.py) is pinned
+    to the C restatement on a band of rows: rows are independent jobs that read input rows y - pad .. y + pad only
+    (_passive.cpp:38-40, 60-62, 372-374), so the band with its halo, matched as a stand-alone image, must reproduce those
+    rows of the full-frame maps bit for bit (ASW plain rows 536..541, GSW rows 300..339 with the left-right check)."""
+    import json
+    from oracle import oracle
+    from simplestereo_amd.synth import make_pair
+    path = os.path.join(GOLDEN, "full_cases.npz")
+    if not os.path.exists(path):
+        pytest.skip("full_cases.npz not generated")
+    maps = np.load(path)
+    meta = json.load(open(os.path.join(GOLDEN, "full_cases.json")))
+    H, W, maxD, seed = meta["F3p"]["frame"]
+    L, R, _ = make_pair(H, W, maxD, seed)
+    import hashlib
+    for cid in maps.files:
+        assert hashlib.sha256(maps[cid].tobytes()).hexdigest() == meta[cid]["sha256"], cid
+        assert hashlib.sha256(L.tobytes() + R.tobytes()).hexdigest() == meta[cid]["input_sha256"], cid
+    p = {k: v for k, v in meta["F3p"]["params"].items() if k != "algo"}
+    pad, r0, rows = p["winSize"] // 2, 536, 6
+    band = oracle.asw(np.ascontiguousarray(L[r0 - pad:r0 + rows + pad]), np.ascontiguousarray(R[r0 - pad:r0 + rows + pad]), hoist=True, **p)
+    assert np.array_equal(band[pad:pad + rows], maps["F3p"][r0:r0 + rows])
+    if "F4" in maps.files:
+        g = {k: v for k, v in meta["F4"]["params"].items() if k != "algo"}
+        pad, r0, rows = g["winSize"] // 2, 300, 40
+        band = oracle.gsw(np.ascontiguousarray(L[r0 - pad:r0 + rows + pad]), np.ascontiguousarray(R[r0 - pad:r0 + rows + pad]), closed=True, **g)
+        assert np.array_equal(band[pad:pad + rows], maps["F4"][r0:r0 + rows])
