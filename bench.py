@@ -730,13 +730,17 @@ def main():
         # what every rank actually ran on, collected on rank 0
         phases = strip_ctx.read_timing() or {}
         strip_ctx.enable_timing(False)
-        my_k = ms[_native.K_ASW_AGG] / max(1, launches[_native.K_ASW_AGG])
+        my_k = ms[_native.K_ASW_AGG] / max(1, args.steps)          # per STEP: the overlapped strip step runs two aggregation launches (interior rows, border bands)
         my_taps = count_taps(H, W, win, maxD, minD, r0, r1 - r0) if r1 > r0 else 0
         mine = {"rank": rank, "device": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(dev),
                 "strip_rows": [r0, r1], "halo_rows": [strip_ctx.h0, strip_ctx.h1],
                 "kernel_ms": my_k, "taps": my_taps,
                 "valu_frac": VALU_OPS_PER_TAP * my_taps / (my_k * 1e-3) / VALU_PEAK_LANEOPS if my_k > 0 else None,
                 "halo_exchange_ms": phases.get("exchange_ms"), "kernels_phase_ms": phases.get("kernels_ms"),
+                "overlapped": phases.get("overlapped"), "interior_rows": strip_ctx.interior, "border_rows": strip_ctx.top + strip_ctx.bot,
+                "interior_ms": phases.get("interior_ms"), "border_ms": phases.get("border_ms"),
+                "halo_exchange_exposed_ms": phases.get("exchange_exposed_ms"),
+                "aggregation_launches_per_step": launches[_native.K_ASW_AGG] / float(max(1, args.steps)),
                 "gather_ms": phases.get("gather_ms"), "messages_sent": len(strip_ctx.sends), "messages_received": len(strip_ctx.recvs)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -763,7 +767,7 @@ def main():
 
     if rank == 0:
         per_step = dt / args.steps
-        k_ms = ms[_native.K_ASW_AGG] / max(1, launches[_native.K_ASW_AGG])       # this rank's strip
+        k_ms = ms[_native.K_ASW_AGG] / max(1, args.steps if use_dist else launches[_native.K_ASW_AGG])       # this rank's strip, per step
         rows_here = r1 - r0
         algo_bytes = ALGO_BYTES_PER_PIXEL * rows_here * W
         taps_here = count_taps(H, W, win, maxD, minD, r0, rows_here)

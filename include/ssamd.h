@@ -99,6 +99,18 @@ int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      double gammaC, double gammaP, int consistent,
                      int16_t *d_disparity, void *stream);
 
+/* ssamd_asw_device on TWO row ranges in one launch: rows [out_row0, skip_row0) and [skip_row0 + skip_rows, out_row0 + out_rows)
+ * are matched, the rows in between are left untouched in d_disparity ([out_rows][width], laid out for the whole range).  For a row
+ * strip of a frame cut across GPUs (simplestereo_amd/strips.py): the interior rows, whose windows stay inside the rows the rank owns,
+ * run as an ordinary ssamd_asw_device call while the halo rows are still in flight over RCCL; the two border bands then take ONE
+ * launch instead of two part-filled ones.  Rows are independent jobs in the reference (_passive.cpp:372-374), so the strip's map does
+ * not depend on the cut.  skip_rows = 0: identical to ssamd_asw_device. */
+int ssamd_asw_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                           int out_row0, int out_rows, int skip_row0, int skip_rows,
+                           int winSize, int maxDisparity, int minDisparity,
+                           double gammaC, double gammaP, int consistent,
+                           int16_t *d_disparity, void *stream);
+
 int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
                      int out_row0, int out_rows,
                      int winSize, int maxDisparity, int minDisparity,

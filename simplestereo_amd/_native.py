@@ -74,6 +74,8 @@ def lib():
     L.ssamd_asw_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_gsw_device.restype = I
     L.ssamd_gsw_device.argtypes = [P, P, I, I, I, I, I, I, I, I, F, I, I, P, P]
+    L.ssamd_asw_device_rows2.restype = I
+    L.ssamd_asw_device_rows2.argtypes = [P, P, I, I, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_exact.restype = I
     L.ssamd_asw_exact.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
     L.ssamd_asw_exact_device.restype = I

@@ -77,11 +77,20 @@ struct AswArgs {
                                  //    fp64 tie-break pass compares them with the winning keys (asw_exact_kernels.hip.h)
     int H, W, win, pad, minD, maxD, row0, rows;
     int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)
+    int yskip_at, yskip;         // ... + yskip for b >= yskip_at: TWO row ranges in one launch (the border rows of a row strip whose
+                                 //     interior rows ran while the halo was in flight, strips.py); yskip = 0: one range
     float kC;                    // -log2(e)/gammaC
     AswGeom g;
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+// output row (of the sub-image) of workgroup row b
+template <typename Args>
+__device__ __forceinline__ int asw_out_row(const Args &A, int b)
+{
+    return A.row0 + b * A.ystep + (b >= A.yskip_at ? A.yskip : 0);
+}
 
 // Matching-cost cap of the reference (std::min(40, ...), _passive.cpp:77).
 static constexpr float ASW_TAD_CAP = 40.0f;
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     int bx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
     const int x0 = bx * Tx;
-    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int y = asw_out_row(A, blockIdx.y);
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
     // no (x,d) pair of this tile has x-d >= 0 (left image border): nothing to aggregate; the empty candidate

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     int bx = blockIdx.x;                          // XCD-aware tile order, see asw_aggregate_kernel
     if ((gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
     const int x0 = bx * Tx;
-    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int y = asw_out_row(A, blockIdx.y);
     const int dlo = A.minD + blockIdx.z * Dc;
     const int dhi = dlo + Dc - 1;
     if (min(x0 + Tx - 1, W - 1) - dlo < 0) {      // no candidate the reference evaluates in this tile

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
     const int Txw = g.Txw, Dc = g.Dc, nLw = g.nLw, nRcw = g.nRcw, nRw = g.nRw, Se = g.Se;
     const int x0 = (blockIdx.x * g.waves + wave) * Txw;
     if (x0 >= W) return;
-    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int y = asw_out_row(A, blockIdx.y);
     const int dlo = A.minD, dhi = dlo + Dc - 1;
     const size_t orow = (size_t)(y - A.row0) * W;
     if (min(x0 + Txw - 1, W - 1) - dlo < 0) {                   // no candidate the reference evaluates in this strip

@@ -47,6 +47,7 @@ struct AswWaveArgs {
     const unsigned char *evol;   // TAD volume (required)
     int erow0, erows, evolW;
     int H, W, win, pad, minD, maxD, row0, rows, ystep;
+    int yskip_at, yskip;         // second row range (AswArgs::yskip)
     float kC;
     AswWaveGeom g;
 };
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
     const int Txw = g.Txw, Dc = g.Dc, nLw = g.nLw, nRcw = g.nRcw, nRw = g.nRw, Se = g.Se;
     const int x0 = (blockIdx.x * g.waves + wave) * Txw;
     if (x0 >= W) return;                                         // (no workgroup barrier anywhere: waves are independent)
-    const int y = A.row0 + blockIdx.y * A.ystep;
+    const int y = asw_out_row(A, blockIdx.y);
     const int dlo = A.minD, dhi = dlo + Dc - 1;
     const size_t orow = (size_t)(y - A.row0) * W;
     if (min(x0 + Txw - 1, W - 1) - dlo < 0) {                   // no candidate the reference evaluates in this strip

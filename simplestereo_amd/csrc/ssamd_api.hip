@@ -989,10 +989,15 @@ int launch_finalize(Ctx &c, int slot, bool lrcheck, int rows, int W, int16_t *d_
 int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, int row0, int rows, int win,
                     int maxD, int minD, double gammaC, double gammaP, int consistent, int16_t *d_disp,
                     float *d_costs, hipStream_t s, bool alternate = false, int16_t *d_raw_right = nullptr, const RemapSrc *rm = nullptr,
-                    bool exact = false)
+                    bool exact = false, int skip_at = 0, int skip = 0)
 {
+    // skip > 0: rows [row0 + skip_at, row0 + skip_at + skip) of the range are NOT matched (ssamd_asw_device_rows2: the two border
+    // bands of a row strip in one launch); buffers stay laid out for the whole range [row0, row0 + rows)
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
+    if (skip < 0 || skip_at < 0 || skip_at + skip > rows) return fail(SSAMD_EINVAL, "bad row gap [%d,%d) in a range of %d rows", skip_at, skip_at + skip, rows);
+    if (skip > 0 && (alternate || exact || d_costs || d_raw_right)) return fail(SSAMD_EINVAL, "two row ranges: plain and consistent matching only");
+    if (skip == rows) return SSAMD_OK;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
     if (exact && (alternate || d_costs)) return fail(SSAMD_EINVAL, "the exact (fp64 tie-break) mode has no alternate-rows form and no cost dump");
     if (maxD < minD) exact = false;                                   // empty candidate loops: nothing to break ties between
@@ -1012,7 +1017,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
     // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
     AswArgs a{};
-    const int grows = alternate ? (rows + 1) / 2 : rows;              // workgroup rows: every row, or the even ones
+    const int grows = alternate ? (rows + 1) / 2 : rows - skip;       // workgroup rows: every row (of both ranges), or the even ones
     if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, grows, win, nD))) return rc;
     // Autotuning (ssamd_autotune): the first call for a problem shape times the best geometry of every class of
     // candidates on the real buffers and keeps the fastest.  Every geometry accumulates the same taps in the same
@@ -1098,6 +1103,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
         a.ystep = alternate ? 2 : 1;
+        a.yskip_at = skip > 0 ? skip_at : 0x7fffffff; a.yskip = skip;
         a.evol = nullptr; a.erow0 = r0; a.erows = r1 - r0; a.evolW = 0;
         // pre-computed truncated-absolute-difference volume for the phase-shifted kernel (asw_tad_volume_kernel);
         // SSAMD_ASW_EVOL=0 keeps the in-kernel e tiles (experiments / tests)
@@ -1168,7 +1174,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs; wa.cost_keys = a.cost_keys;
                 wa.evol = a.evol; wa.erow0 = a.erow0; wa.erows = a.erows; wa.evolW = a.evolW;
                 wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
-                wa.ystep = a.ystep; wa.kC = a.kC;
+                wa.ystep = a.ystep; wa.kC = a.kC; wa.yskip_at = a.yskip_at; wa.yskip = a.yskip;
                 auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
                                        : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
                 // build rounds known at compile time (straight-line build): the common combinations
@@ -1222,7 +1228,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 // (tests/test_gpu_asw.py).  Worth ~4 % at 8.44 rounds, nothing beyond a few dozen; SSAMD_ASW_TAIL=0 / 1 forces.
                 int rows_main = grows;
                 AswGeom tail_g;
-                if (!alternate && tune().asw_tail != 0 && g.XG >= 4) {
+                if (!alternate && skip == 0 && tune().asw_tail != 0 && g.XG >= 4) {
                     // workgroups in flight at a time: the device's CUs x the tile's residency (168 VGPRs -> three waves per SIMD;
                     // the tile's LDS).  One per CU for the 9- to 12-wave tiles of the headline configurations.
                     const int per_simd = (g.threads / 64 + 3) / 4;
@@ -1356,7 +1362,28 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     }
     const bool direct = is_direct(a.g);
     if (exact && (rc = asw_exact_pass(c, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent != 0, s))) return rc;
-    if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
+    if (!direct && skip > 0) {
+        // decode / left-right check of the two bands only (row-local: _passive.cpp:251-285); the rows between keep what the
+        // interior call wrote
+        const auto band = [&](int b0, int nb) -> int {
+            if (nb <= 0) return SSAMD_OK;
+            const size_t off = (size_t)b0 * W;
+            Timed t(c, s, SSAMD_K_ASW_FIN);
+            if (consistent) {
+                const size_t lds = (((size_t)W * 2 + 15) & ~(size_t)15) + W;
+                if (int grc = grant_dyn_lds(c, (const void *)lr_check_fill_kernel, (int)lds)) return grc;
+                hipLaunchKernelGGL(lr_check_fill_kernel, dim3(nb), dim3(256), lds, s, (const u64 *)c.keyL.ptr + off, (const u64 *)c.keyR.ptr + off,
+                                   d_disp + off, nb, W);
+            } else {
+                const long long n = (long long)nb * W;
+                hipLaunchKernelGGL(wta_decode_kernel, dim3((int)std::min<long long>((n + 255) / 256, 256 * 8)), dim3(256), 0, s,
+                                   (const u64 *)c.keyL.ptr + off, d_disp + off, nb, W, 0);
+            }
+            HIP_TRY(hipGetLastError());
+            return SSAMD_OK;
+        };
+        if ((rc = band(0, skip_at)) || (rc = band(skip_at + skip, rows - skip_at - skip))) return rc;
+    } else if (!direct && (rc = launch_finalize(c, SSAMD_K_ASW_FIN, consistent != 0, rows, W, d_disp, s, d_raw_right))) return rc;
     if (alternate && rows > 1) {
         // odd rows: candidates bounded by the exact rows above and below (asw_alt_kernels.hip.h).  With an
         // empty disparity range the decode already wrote x everywhere and the fill reproduces it.
@@ -1967,6 +1994,22 @@ int ssamd_asw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream);
+}
+
+int ssamd_asw_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                           int skip_row0, int skip_rows, int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP,
+                           int consistent, int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    if (skip_rows < 0 || (skip_rows > 0 && (skip_row0 < out_row0 || skip_row0 + skip_rows > out_row0 + out_rows)))
+        return fail(SSAMD_EINVAL, "the skipped rows [%d,%d) must lie inside the output rows [%d,%d)", skip_row0, skip_row0 + skip_rows,
+                    out_row0, out_row0 + out_rows);
+    return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity, gammaC, gammaP,
+                           consistent, d_disparity, nullptr, (hipStream_t)stream, false, nullptr, nullptr, false,
+                           skip_rows > 0 ? skip_row0 - out_row0 : 0, skip_rows);
 }
 
 int ssamd_asw_exact_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,

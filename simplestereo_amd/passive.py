@@ -297,11 +297,13 @@ class StereoASW():
                 _raise_native(e)
         return out
 
-    def _compute_device(self, t1, t2, out_row0=0, out_rows=None, row_parity=0):
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None, row_parity=0, out=None, skip=None):
         """Operands already in HBM (torch tensors): returns a torch.int16 tensor on the device.
         Rows [out_row0, out_row0+out_rows) of the given (sub-)image are matched.  ``row_parity`` (alternate=True only):
         parity of the sub-image's first row in the whole image, whose even rows are the exactly matched ones; such a
-        sub-image carries ``winSize // 2 + 1`` halo rows."""
+        sub-image carries ``winSize // 2 + 1`` halo rows.  ``out``: a contiguous int16 [out_rows, W] tensor to write into
+        instead of a new one.  ``skip = (row, n)``: rows [row, row + n) of the range are left untouched in ``out`` and the two
+        bands either side of them run as ONE launch (``ssamd_asw_device_rows2``; row strips, strips.py)."""
         import torch
         lib = _native.lib()
         win, maxd, mind, gc, gp, cons = self._params()
@@ -311,10 +313,19 @@ class StereoASW():
         H, W = int(a.shape[0]), int(a.shape[1])
         rows = H - out_row0 if out_rows is None else int(out_rows)
         alt = self._alternate(cons)
-        out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        if out is None:
+            out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        elif out.dtype != torch.int16 or tuple(out.shape) != (rows, W) or not out.is_contiguous() or out.device != a.device:
+            raise ValueError("out must be a contiguous int16 [out_rows, W] tensor on the images' device")
         with torch.cuda.device(a.device):
             stream = torch.cuda.current_stream(a.device).cuda_stream
             try:
+                if skip is not None and skip[1] > 0:
+                    if alt or self._exact():
+                        raise ValueError("two row ranges: not with alternate=True / exact=True")
+                    _native.check(lib.ssamd_asw_device_rows2(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, int(skip[0]), int(skip[1]),
+                                                             win, maxd, mind, gc, gp, cons, out.data_ptr(), ctypes.c_void_p(stream)))
+                    return out
                 if alt:
                     _native.check(lib.ssamd_asw_alternate_rows_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows,
                                                                       int(row_parity) & 1, win, maxd, mind, gc, gp, cons,

@@ -163,7 +163,7 @@ class StripContext:
     through host buffers; the kernels still run on `device`.
     """
 
-    def __init__(self, matcher, height, width, rank, world_size, device, group=None):
+    def __init__(self, matcher, height, width, rank, world_size, device, group=None, overlap=True):
         import torch
         import torch.distributed as dist
         self.matcher, self.H, self.W = matcher, int(height), int(width)
@@ -187,67 +187,125 @@ class StripContext:
                     torch.empty((n, self.W, 3), dtype=torch.uint8, device=cdev))
         self.send_bufs = [pair(hi - lo) for _, lo, hi in self.sends]
         self.recv_bufs = [pair(hi - lo) for _, lo, hi in self.recvs] if self.staged else None
+        # the message list of a step never changes (fixed buffers, fixed peers): built once
+        self._ops = []
+        if self.world > 1 and dist.is_initialized():
+            for (dst, lo, hi), (bl, br) in zip(self.sends, self.send_bufs):
+                self._ops.append(dist.P2POp(dist.isend, bl, dst, group=self.group))
+                self._ops.append(dist.P2POp(dist.isend, br, dst, group=self.group))
+            for k, (src, lo, hi) in enumerate(self.recvs):
+                tl, tr = self.recv_bufs[k] if self.staged else (self.subL[lo:hi], self.subR[lo:hi])
+                self._ops.append(dist.P2POp(dist.irecv, tl, src, group=self.group))
+                self._ops.append(dist.P2POp(dist.irecv, tr, src, group=self.group))
         self.rows_max = -(-self.H // self.world)
         self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=cdev)
         self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=cdev)
         self.full = torch.empty((self.H, self.W), dtype=torch.int16, device=self.device)
         self.backend = backend
+        # Overlap (round 5): the rows whose windows stay inside the rows this rank OWNS do not need the halo -- they are matched
+        # while the halo rows are in flight on a side stream; the (at most 2 * pad) border rows follow as ONE launch
+        # (ssamd_asw_device_rows2).  Rows are independent jobs (_passive.cpp:372-374): the strip's map does not depend on the cut.
+        n = self.r1 - self.r0
+        self.top = min(self.pad, n) if self.h0 < self.r0 else 0        # rows that read halo rows above / below
+        self.bot = min(self.pad, n - self.top) if self.h1 > self.r1 else 0
+        self.interior = n - self.top - self.bot
+        self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ == "StereoASW" and
+                            not getattr(matcher, "alternate", False) and not getattr(matcher, "exact", False) and
+                            self.world > 1 and self._ops and self.interior > 0 and self.top + self.bot > 0)
+        self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self.strip_out = torch.empty((n, self.W), dtype=torch.int16, device=self.device) if self.overlap else None
         self._timing = None           # list of per-step event tuples while enable_timing() is on (GPU devices only)
 
     def enable_timing(self, on=True):
-        """Record device events around the three phases of every step (halo exchange incl. the two strip copies,
-        kernels, gather) on the current stream; read_timing() returns their totals."""
+        """Record device events around the phases of every step (halo exchange incl. the strip copies, kernels, gather) on
+        the streams they run on; read_timing() returns their per-step averages."""
         self._timing = [] if on and self.device.type == "cuda" else None
 
     def read_timing(self):
-        """{'steps', 'exchange_ms', 'kernels_ms', 'gather_ms'}: per-step averages since enable_timing()"""
+        """{'steps', 'exchange_ms', 'kernels_ms', 'gather_ms'} per step since enable_timing(); with the overlapped step also
+        'interior_ms' (kernels that ran while the halo was in flight), 'border_ms' and 'exchange_exposed_ms' = the part of
+        the exchange that was NOT hidden under the interior rows (0 when it ended first)."""
         import torch
         if not self._timing:
             return None
         torch.cuda.synchronize(self.device)
         n = len(self._timing)
-        ex = sum(a.elapsed_time(b) for a, b, c, d in self._timing) / n
-        ke = sum(b.elapsed_time(c) for a, b, c, d in self._timing) / n
-        ga = sum(c.elapsed_time(d) for a, b, c, d in self._timing) / n
-        return {"steps": n, "exchange_ms": ex, "kernels_ms": ke, "gather_ms": ga}
+        out = {"steps": n, "overlapped": bool(self._timing[0].get("x0") is not None)}
+        if out["overlapped"]:
+            out["exchange_ms"] = sum(t["x0"].elapsed_time(t["x1"]) for t in self._timing) / n
+            out["interior_ms"] = sum(t["e1"].elapsed_time(t["ei"]) for t in self._timing) / n
+            out["border_ms"] = sum(t["ei"].elapsed_time(t["e2"]) for t in self._timing) / n
+            out["exchange_exposed_ms"] = sum(max(0.0, t["ei"].elapsed_time(t["x1"])) for t in self._timing) / n
+            out["copies_ms"] = sum(t["e0"].elapsed_time(t["e1"]) for t in self._timing) / n
+        else:
+            out["exchange_ms"] = sum(t["e0"].elapsed_time(t["e1"]) for t in self._timing) / n
+        out["kernels_ms"] = sum(t["e1"].elapsed_time(t["e2"]) for t in self._timing) / n
+        out["gather_ms"] = sum(t["e2"].elapsed_time(t["e3"]) for t in self._timing) / n
+        return out
 
-    def _mark(self):
+    def _mark(self, stream=None):
         import torch
         e = torch.cuda.Event(enable_timing=True)
-        e.record(torch.cuda.current_stream(self.device))
+        e.record(stream if stream is not None else torch.cuda.current_stream(self.device))
         return e
+
+    def _exchange(self, own_left, own_right):
+        """the halo messages of one step on the CURRENT stream: fill the send buffers, one batched isend / irecv group, unpack"""
+        import torch.distributed as dist
+        for (dst, lo, hi), (bl, br) in zip(self.sends, self.send_bufs):
+            bl.copy_(own_left[lo:hi])
+            br.copy_(own_right[lo:hi])
+        for req in dist.batch_isend_irecv(self._ops):
+            req.wait()
+        if self.staged:
+            for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
+                self.subL[lo:hi].copy_(tl)
+                self.subR[lo:hi].copy_(tr)
 
     def step(self, own_left, own_right, gather=True):
         import torch
-        import torch.distributed as dist
         timing = self._timing is not None
-        e0 = self._mark() if timing else None
+        t = {"e0": self._mark()} if timing else None
         o0, o1 = self.r0 - self.h0, self.r1 - self.h0
         self.subL[o0:o1].copy_(own_left)
         self.subR[o0:o1].copy_(own_right)
-        if self.world > 1 and (self.sends or self.recvs):
-            ops = []
-            for (dst, lo, hi), (bl, br) in zip(self.sends, self.send_bufs):
-                bl.copy_(own_left[lo:hi])
-                br.copy_(own_right[lo:hi])
-                ops.append(dist.P2POp(dist.isend, bl, dst, group=self.group))
-                ops.append(dist.P2POp(dist.isend, br, dst, group=self.group))
-            for k, (src, lo, hi) in enumerate(self.recvs):
-                tl, tr = self.recv_bufs[k] if self.staged else (self.subL[lo:hi], self.subR[lo:hi])
-                ops.append(dist.P2POp(dist.irecv, tl, src, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, tr, src, group=self.group))
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if self.staged:
-                for (src, lo, hi), (tl, tr) in zip(self.recvs, self.recv_bufs):
-                    self.subL[lo:hi].copy_(tl)
-                    self.subR[lo:hi].copy_(tr)
-        e1 = self._mark() if timing else None
-        strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0, self.h0 & 1)
-        e2 = self._mark() if timing else None
+        if self.overlap:
+            main = torch.cuda.current_stream(self.device)
+            copied = torch.cuda.Event()
+            copied.record(main)
+            if timing:
+                t["e1"] = self._mark()
+            # interior rows first (asynchronous launches on the main stream) ...
+            self.matcher._compute_device(self.subL, self.subR, out_row0=o0 + self.top, out_rows=self.interior,
+                                         out=self.strip_out[self.top:self.top + self.interior])
+            if timing:
+                t["ei"] = self._mark()
+            # ... the halo meanwhile on the side stream (RCCL orders its work behind the stream that is current at the call)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(copied)
+                if timing:
+                    t["x0"] = self._mark(self.side)
+                self._exchange(own_left, own_right)
+                if timing:
+                    t["x1"] = self._mark(self.side)
+                arrived = torch.cuda.Event()
+                arrived.record(self.side)
+            main.wait_event(arrived)
+            # ... then the border bands, one launch
+            strip = self.matcher._compute_device(self.subL, self.subR, out_row0=o0, out_rows=self.r1 - self.r0, out=self.strip_out,
+                                                 skip=(o0 + self.top, self.interior))
+        else:
+            if self._ops:
+                self._exchange(own_left, own_right)
+            if timing:
+                t["e1"] = self._mark()
+            strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0, self.h0 & 1)
+        if timing:
+            t["e2"] = self._mark()
         out = self._gather(strip) if gather else strip
         if timing:
-            self._timing.append((e0, e1, e2, self._mark()))
+            t["e3"] = self._mark()
+            self._timing.append(t)
         return out
 
     def _gather(self, strip):

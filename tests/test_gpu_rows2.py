@@ -1,0 +1,54 @@
+"""GPU tier: ssamd_asw_device_rows2 -- two row ranges of a sub-image in ONE launch (the border bands of a row strip whose
+interior rows were matched while the halo was in flight, simplestereo_amd/strips.py).  Rows are the reference's independent jobs
+(_passive.cpp:372-374): whatever the cut, the rows written must equal those of one launch over the whole range, and the rows
+in between must stay untouched."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W,params", [
+    (80, 300, dict(winSize=35, maxDisparity=16)),                          # wave kernel, direct write
+    (80, 300, dict(winSize=35, maxDisparity=17, consistent=True)),         # six-per-lane wave kernel, keys + left-right check per band
+    (60, 400, dict(winSize=35, maxDisparity=100, minDisparity=2)),         # phase-shifted kernel
+    (60, 400, dict(winSize=21, maxDisparity=150, consistent=True)),        # several tiles, keys
+    (50, 120, dict(winSize=5, maxDisparity=60)),                           # round-1 kernel (window of one chunk)
+])
+def test_two_row_ranges_equal_one_launch(H, W, params):
+    import torch
+    import simplestereo_amd as ss
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(H, W, params["maxDisparity"], 13)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(**params)
+    row0, rows = 3, H - 7
+    want = m._compute_device(tL, tR, out_row0=row0, out_rows=rows)
+    for skip0, nskip in ((row0 + 9, rows - 20), (row0, 11), (row0 + rows - 5, 5), (row0 + 4, 0), (row0, rows)):
+        out = torch.full((rows, W), -7, dtype=torch.int16, device="cuda")
+        got = m._compute_device(tL, tR, out_row0=row0, out_rows=rows, out=out, skip=(skip0, nskip))
+        assert got.data_ptr() == out.data_ptr()
+        a, b = skip0 - row0, skip0 - row0 + nskip
+        if nskip == 0:
+            assert torch.equal(out, want)
+            continue
+        assert torch.equal(out[:a], want[:a]) and torch.equal(out[b:], want[b:]), (params, skip0, nskip)
+        assert bool((out[a:b] == -7).all()), "rows between the two ranges were written"
+        # ... and the interior rows written by an ordinary call into the same buffer complete the strip
+        m._compute_device(tL, tR, out_row0=skip0, out_rows=nskip, out=out[a:b])
+        assert torch.equal(out, want)
+
+
+def test_two_row_ranges_argument_errors():
+    import torch
+    import simplestereo_amd as ss
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(40, 100, 16, 2)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.empty((30, 100), dtype=torch.int16, device="cuda")
+    with pytest.raises(ValueError):
+        ss.passive.StereoASW(maxDisparity=16, winSize=9)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out, skip=(2, 5))
+    with pytest.raises(ValueError):
+        ss.passive.StereoASW(maxDisparity=16, winSize=9, exact=True)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out, skip=(8, 5))
+    with pytest.raises(ValueError):
+        ss.passive.StereoASW(maxDisparity=16, winSize=9)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out[:, :50])

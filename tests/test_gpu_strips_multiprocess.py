@@ -32,7 +32,7 @@ def _worker(rank, world, port, case, q):
         algo, H, W, params = case
         L, R, _ = make_pair(H, W, params["maxDisparity"], 11)
         dev = torch.device("cuda", 0)
-        m = (ss.passive.StereoASW if algo == "asw" else ss.passive.StereoGSW)(**params)
+        m = (ss.passive.StereoASW if algo == "asw" else ss.passive.StereoGSW)(**{k: v for k, v in params.items() if not k.startswith("_")})
         r0, r1 = strips.strip_bounds(H, world, rank)
         ownL = torch.from_numpy(np.ascontiguousarray(L[r0:r1])).to(dev)
         ownR = torch.from_numpy(np.ascontiguousarray(R[r0:r1])).to(dev)
@@ -42,7 +42,8 @@ def _worker(rank, world, port, case, q):
         for _ in range(2):                                   # the context is reusable across frames
             full = ctx.step(ownL, ownR).cpu().numpy().copy()
         want = m.compute(L, R)                               # whole frame, one process
-        q.put((rank, bool(np.array_equal(full, want)), int((full != want).sum())))
+        q.put((rank, bool(np.array_equal(full, want)) and (params.get("_overlap") is None or ctx.overlap == params["_overlap"]),
+               int((full != want).sum()) if ctx.overlap == params.get("_overlap", ctx.overlap) else "overlap=%r" % ctx.overlap))
     except Exception as e:      # noqa: BLE001
         q.put((rank, False, repr(e)))
     finally:
@@ -50,9 +51,15 @@ def _worker(rank, world, port, case, q):
 
 
 @pytest.mark.parametrize("world,case", [
-    (2, ("asw", 61, 200, dict(winSize=21, maxDisparity=40, consistent=True))),
+    (2, ("asw", 61, 200, dict(winSize=21, maxDisparity=40, consistent=True, _overlap=True))),
     (3, ("asw", 50, 160, dict(winSize=35, maxDisparity=24, minDisparity=2))),      # strips thinner than the halo
     (2, ("gsw", 45, 150, dict(winSize=11, maxDisparity=30))),
+    # round 5, the overlapped step: interior rows matched while the halo is in flight, the border bands as one launch --
+    # direct-write path (one disparity chunk, no right pass) and keyed path; a middle rank with two bands; the wave kernel
+    (2, ("asw", 90, 200, dict(winSize=15, maxDisparity=40, _overlap=True))),
+    (3, ("asw", 120, 260, dict(winSize=15, maxDisparity=70, consistent=True, _overlap=True))),
+    (3, ("asw", 96, 300, dict(winSize=35, maxDisparity=16, minDisparity=1, _overlap=False))),       # 32-row strips: no row is free of the 17-row halo
+    (2, ("asw", 100, 300, dict(winSize=35, maxDisparity=16, _overlap=True))),
     (3, ("asw", 47, 160, dict(winSize=11, maxDisparity=24, alternate=True))),      # strips of 16 / 16 / 15 rows: odd and even starts
     # BASELINE config 5's partition: eight ranks, 4096 columns, D 0..256, win 35 (the 88 x 260 tiles of the 4K launch); 136
     # rows = eight strips of 17 rows = exactly the halo, so every interior rank receives both halos whole from its neighbours
