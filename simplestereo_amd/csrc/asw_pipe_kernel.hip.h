@@ -38,6 +38,7 @@
 // wR and no swizzle arithmetic.
 #pragma once
 #include "asw_kernels.hip.h"
+#include "lab_kernels.hip.h"
 
 #ifndef SSAMD_PIPE_SENTINEL       // 0: the round-2 weight build with masks (A/B builds of tools/build_variants.sh)
 #define SSAMD_PIPE_SENTINEL 1
@@ -56,27 +57,40 @@ namespace ssamd {
 // reads), every thread then produces whole dwords (4 disparities) of one column, and the 64 x Se byte block -- a
 // contiguous piece of the volume -- is written with consecutive lanes on consecutive dwords.
 static constexpr int TADV_COLS = 64;
-__global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__restrict__ recL, const PixRec *__restrict__ recR,
-                                                             unsigned char *__restrict__ evol, int W, int pad, int minD, int Dc,
-                                                             int Se, int erow0, int erows, int evolW, int rd = 4)
+// One tile (bx, by, bz) of the volume.  BYTES: the pixels come straight from the caller's uint8 [H][W][3] images instead of the
+// records -- the volume then does not depend on the Lab conversion and both run in ONE launch (asw_prepass_kernel below).
+template <bool BYTES>
+__device__ __forceinline__ void asw_tad_tile(const void *__restrict__ srcL, const void *__restrict__ srcR, unsigned char *__restrict__ evol,
+                                             int W, int pad, int minD, int Dc, int Se, int erow0, int erows, int evolW, int rd, long long npix_total,
+                                             int bx, int by, int bz, char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *const sL = reinterpret_cast<uint32_t *>(smem);                 // [TADV_COLS]
     uint32_t *const sR = sL + TADV_COLS;                                     // [TADV_COLS + Dc]: right columns u0 - dhi .. u0 + 63 - dlo
-    const int r = erow0 + blockIdx.y, z = blockIdx.z, uc0 = blockIdx.x * TADV_COLS;
+    const int r = erow0 + by, z = bz, uc0 = bx * TADV_COLS;
     const int P = Se >> 2, dlo = minD + z * Dc, dhi = dlo + Dc - 1;
     const int u0 = uc0 - pad, xr0 = u0 - dhi;
-    const PixRec *const rowL = recL + (size_t)r * W, *const rowR = recR + (size_t)r * W;
+    auto pixel = [&](const void *src, int col) -> uint32_t {
+        const size_t q = (size_t)r * W + col;
+        if constexpr (BYTES) {
+            typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+            const uint8_t *const b = reinterpret_cast<const uint8_t *>(src) + 3 * q;
+            // (the 4-byte read of the image's last pixel would run one byte past the buffer)
+            return (long long)q + 1 < npix_total ? (*reinterpret_cast<const u32_unaligned *>(b) & 0xffffffu)
+                                                 : ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16));
+        } else {
+            return reinterpret_cast<const PixRec *>(src)[q].bgrx;
+        }
+    };
     for (int k = threadIdx.x; k < 2 * TADV_COLS + Dc; k += blockDim.x) {
         const bool isL = k < TADV_COLS;
         const int col = isL ? u0 + k : xr0 + (k - TADV_COLS);
         // bit 31 marks a column outside the image (pixel bytes never set it): its e values are 0
-        const uint32_t v = (unsigned)col < (unsigned)W ? (isL ? rowL : rowR)[col].bgrx : 0x80000000u;
+        const uint32_t v = (unsigned)col < (unsigned)W ? pixel(isL ? srcL : srcR, col) : 0x80000000u;
         (isL ? sL : sR)[isL ? k : k - TADV_COLS] = v;
     }
     __syncthreads();
     const int ncols = min(TADV_COLS, evolW - uc0);
-    uint32_t *const out = reinterpret_cast<uint32_t *>(evol + (((size_t)z * erows + blockIdx.y) * (size_t)evolW + uc0) * Se);
+    uint32_t *const out = reinterpret_cast<uint32_t *>(evol + (((size_t)z * erows + by) * (size_t)evolW + uc0) * Se);
     // rd = 4: dword `slot` of a column holds the disparities dlo + 4 slot + 0..3;  rd = 6 (asw_wave6_kernel.hip.h): a
     // disparity group is an 8-byte slot, dword 2 g holds dlo + 6 g + 0..3 and dword 2 g + 1 holds dlo + 6 g + 4, 5
     auto dword = [&](int c, int slot, uint32_t lp) {
@@ -109,6 +123,56 @@ __global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__res
         const int c = k / P, slot = k - c * P;
         out[k] = dword(c, slot, sL[c]);
     }
+}
+
+__global__ __launch_bounds__(256) void asw_tad_volume_kernel(const PixRec *__restrict__ recL, const PixRec *__restrict__ recR,
+                                                             unsigned char *__restrict__ evol, int W, int pad, int minD, int Dc,
+                                                             int Se, int erow0, int erows, int evolW, int rd = 4)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asw_tad_tile<false>(recL, recR, evol, W, pad, minD, Dc, Se, erow0, erows, evolW, rd, 0, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// K0 + K0e in ONE launch (round 5): the first `lab_blocks` workgroups convert the pixels of the rows [erow0, erow0 + erows) of both
+// images into records (bgr2lab_records_pair_kernel's job, same code), the others each build one tile of the volume from the
+// images' bytes.  The two jobs do not depend on each other, so a small-frame call is two dependent launches instead of three
+// (a launch-to-launch dependency costs more than either kernel at Tsukuba size).  bgrL / bgrR: the sub-image's row 0.
+struct AswPrepassArgs {
+    const uint8_t *bgrL, *bgrR;
+    PixRec *recL, *recR;
+    unsigned char *evol;
+    long long npix_total;            // pixels of the whole sub-image (bounds of the 4-byte pixel reads)
+    int W, pad, minD, Dc, Se, erow0, erows, evolW, rd;
+    int lab_blocks, ex, ey;          // grid: lab_blocks + ex * ey * ez workgroups
+};
+__global__ __launch_bounds__(256) void asw_prepass_kernel(const AswPrepassArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < P.lab_blocks) {
+        const long long np = (long long)P.erows * P.W, first = (long long)P.erow0 * P.W;
+        const uint8_t *const bl = P.bgrL + 3 * first, *const br = P.bgrR + 3 * first;
+        PixRec *const rl = P.recL + first, *const rr = P.recR + first;
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < 2 * np; q += (long long)P.lab_blocks * blockDim.x) {
+            const bool right = q >= np;
+            const long long p = right ? q - np : q;
+            const uint8_t *const bgr = right ? br : bl;
+            uint32_t B, G, R;
+            if (p + 1 < np) {
+                const uint32_t v = *reinterpret_cast<const u32_unaligned *>(bgr + 3 * p);
+                B = v & 0xff; G = (v >> 8) & 0xff; R = (v >> 16) & 0xff;
+            } else {
+                B = bgr[3 * p]; G = bgr[3 * p + 1]; R = bgr[3 * p + 2];
+            }
+            PixRec o;
+            bgr_to_lab(B, G, R, o.L, o.a, o.b);
+            o.bgrx = B | (G << 8) | (R << 16);
+            (right ? rr : rl)[p] = o;
+        }
+        return;
+    }
+    const int b = (int)blockIdx.x - P.lab_blocks, bx = b % P.ex, by = (b / P.ex) % P.ey, bz = b / (P.ex * P.ey);
+    asw_tad_tile<true>(P.bgrL, P.bgrR, P.evol, P.W, P.pad, P.minD, P.Dc, P.Se, P.erow0, P.erows, P.evolW, P.rd, P.npix_total, bx, by, bz, smem);
 }
 
 // (A 6-column register tile -- 48 accumulators, 128 VGPRs, FOUR waves per SIMD in 1024-thread groups, right weights

@@ -73,6 +73,7 @@ struct Tuning {
     int lds_relax = 1;                // 0: a phase-shifted tile must fit LDS with its staged colour bytes even when the TAD volume makes them unnecessary
     int wave_creg = 1;                // 0: the wave kernel keeps its window centres in LDS (round-3 form)
     int asw_tail = -1;                // -1: the host decides; 0: never split the last partial round of workgroups into half-width tiles; 1: whenever possible
+    int prepass_fuse = 1;             // 0: Lab records and TAD volume as two dependent launches (the form of rounds 2-4)
     int exact_tol = 128;              // fp64 tie-break pass: candidates within this many ulps of the winning cost image are re-evaluated
     int exact_cap = 0;                // 0 unset: queue capacity of the tie-break pass in entries (test hook: a tiny queue overflows)
 };
@@ -104,6 +105,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_TAIL") t.asw_tail = num(-1);
     else if (name == "SSAMD_ASW_WAVE_CREG") t.wave_creg = num(1);
     else if (name == "SSAMD_ASW_LDS_RELAX") t.lds_relax = num(1);
+    else if (name == "SSAMD_ASW_PREPASS_FUSE") t.prepass_fuse = num(1);
     else if (name == "SSAMD_EXACT_TOL") t.exact_tol = v ? std::max(0, atoi(v)) : 128;
     else if (name == "SSAMD_EXACT_CAP") t.exact_cap = v ? std::max(1, atoi(v)) : 0;
     else return false;
@@ -114,7 +116,7 @@ const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_A
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
                                     "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG", "SSAMD_ASW_LDS_RELAX",
-                                    "SSAMD_EXACT_TOL", "SSAMD_EXACT_CAP"};
+                                    "SSAMD_EXACT_TOL", "SSAMD_EXACT_CAP", "SSAMD_ASW_PREPASS_FUSE"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -1082,18 +1084,24 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         const float *d_prox = nullptr;
         if ((rc = get_prox(c, win, gammaP, s, &d_prox))) return rc;
         const int r0 = std::max(0, row0 - p), r1 = std::min(H, row0 + rows + p);
-        {       // Lab records of both images, one launch
-            const long long np2 = (long long)(r1 - r0) * W;
-            const int blocks = (int)std::min<long long>((2 * np2 + 255) / 256, 256 * 8);
+        const long long np2 = (long long)(r1 - r0) * W;
+        const int lab_blocks = (int)std::min<long long>((2 * np2 + 255) / 256, 256 * 8);
+        auto launch_lab = [&]() -> int {       // Lab records of both images, one launch
             Timed t(c, s, SSAMD_K_LAB);
             if (rm)
-                hipLaunchKernelGGL(remap_lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, *rm, (PixRec *)c.recL.ptr, (PixRec *)c.recR.ptr,
+                hipLaunchKernelGGL(remap_lab_records_pair_kernel, dim3(lab_blocks), dim3(256), 0, s, *rm, (PixRec *)c.recL.ptr, (PixRec *)c.recR.ptr,
                                    (long long)r0 * W, np2);
             else
-                hipLaunchKernelGGL(bgr2lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3, dR + (size_t)r0 * W * 3,
+                hipLaunchKernelGGL(bgr2lab_records_pair_kernel, dim3(lab_blocks), dim3(256), 0, s, dL + (size_t)r0 * W * 3, dR + (size_t)r0 * W * 3,
                                    (PixRec *)c.recL.ptr + (size_t)r0 * W, (PixRec *)c.recR.ptr + (size_t)r0 * W, np2);
             HIP_TRY(hipGetLastError());
-        }
+            return SSAMD_OK;
+        };
+        // Round 5: when the call goes straight to its final geometry (no trial launches) and the images are plain byte arrays, the
+        // records are NOT launched here: the TAD volume is then built from the images' bytes, independent of the records, and both
+        // jobs share one launch (asw_prepass_kernel, see prepare_evol) -- two dependent launches per call instead of three.
+        bool lab_pending = trial.empty() && !rm && tune().prepass_fuse != 0;
+        if (!lab_pending && (rc = launch_lab())) return rc;
 
         a.recL = (const PixRec *)c.recL.ptr; a.recR = (const PixRec *)c.recR.ptr;
         a.prox = d_prox;
@@ -1160,6 +1168,25 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             Timed t(c, s, SSAMD_K_LAB);
             const dim3 egrid((unsigned)((evolW + TADV_COLS - 1) / TADV_COLS), (unsigned)(r1 - r0), (unsigned)chunks);
             const size_t elds = (size_t)(2 * TADV_COLS + Dc) * 4;
+            const long long tiles = (long long)egrid.x * egrid.y * egrid.z;
+            if (lab_pending && tiles + lab_blocks < (1ll << 31)) {
+                AswPrepassArgs pa;
+                pa.bgrL = dL; pa.bgrR = dR; pa.recL = (PixRec *)c.recL.ptr; pa.recR = (PixRec *)c.recR.ptr;
+                pa.evol = (unsigned char *)c.evol.ptr; pa.npix_total = (long long)H * W;
+                pa.W = W; pa.pad = p; pa.minD = minD; pa.Dc = Dc; pa.Se = Se; pa.erow0 = r0; pa.erows = r1 - r0; pa.evolW = evolW;
+                pa.rd = g.wave_rx ? wa.g.RD : 4;
+                pa.lab_blocks = lab_blocks; pa.ex = (int)egrid.x; pa.ey = (int)egrid.y;
+                if (int grc = grant_dyn_lds(c, (const void *)asw_prepass_kernel, (int)elds)) return grc;
+                hipLaunchKernelGGL(asw_prepass_kernel, dim3((unsigned)(tiles + lab_blocks)), dim3(256), elds, s, pa);
+                HIP_TRY(hipGetLastError());
+                lab_pending = false;
+                return SSAMD_OK;
+            }
+            if (lab_pending) {                   // (cannot share a launch: records first, as in rounds 2-4)
+                lab_pending = false;
+                if (int lrc = launch_lab()) return lrc;
+            }
+            if (int grc = grant_dyn_lds(c, (const void *)asw_tad_volume_kernel, (int)elds)) return grc;
             hipLaunchKernelGGL(asw_tad_volume_kernel, egrid, dim3(256), elds, s, (const PixRec *)c.recL.ptr, (const PixRec *)c.recR.ptr,
                                (unsigned char *)c.evol.ptr, W, p, minD, Dc, Se, r0, r1 - r0, evolW, g.wave_rx ? wa.g.RD : 4);
             HIP_TRY(hipGetLastError());
@@ -1355,6 +1382,10 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 }
                 final_geom = g2;
                 if ((rc = prepare_evol(final_geom))) return rc;
+            }
+            if (lab_pending) {                   // no volume for this call (in-kernel e tiles, round-1 kernel): the records on their own
+                lab_pending = false;
+                if ((rc = launch_lab())) return rc;
             }
             Timed t(c, s, SSAMD_K_ASW_AGG);
             if ((rc = launch(final_geom))) return rc;

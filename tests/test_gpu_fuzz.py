@@ -57,13 +57,21 @@ def test_asw_fuzz_vs_oracle(case, ss):
     p = dict(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=float(3 + seed % 9), gammaP=float(5 + seed % 20))
     d = ss.passive.StereoASW(**p).compute(a, b)
     ref, cref = oracle.asw(a, b, return_costs=True, **p)
-    bad = 0
+    bad = ties = 0
     for y, x in np.argwhere(np.abs(d.astype(np.int32) - ref) > 1):
         row = cref[y, x]
         cg, cr = row[d[y, x] - minD], row[ref[y, x] - minD]
-        if not (np.isfinite(cg) and abs(cg - cr) <= 1e-6 * max(1.0, abs(cr))):
+        if np.isfinite(cg) and abs(cg - cr) <= 1e-6 * max(1.0, abs(cr)):
+            ties += 1
+        else:
             bad += 1
+    # the exempted pixels are COUNTED (round 5): off by more than one level from the oracle's map although the oracle's own
+    # fp64 costs of the two choices agree to 1e-6 -- at most 0.5 % of the frame here; StereoASW(exact=True) removes all but
+    # the exactly equal ones (tests/test_gpu_exact.py)
+    print("fuzz %s: bad-1.0 pixels %d + %d numerical ties of the oracle, of %d" % (case, bad, ties, H * W))
     assert bad <= max(1, 0.005 * H * W), (case, bad)
+    assert ties <= max(2, 0.005 * H * W), (case, ties)
+    assert bad + ties <= max(2, 0.005 * H * W), (case, bad, ties)      # north_star's bar with NO exclusion
 
 
 def _gpu_argmins(a, b, p):

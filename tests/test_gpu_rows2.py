@@ -52,3 +52,41 @@ def test_two_row_ranges_argument_errors():
         ss.passive.StereoASW(maxDisparity=16, winSize=9, exact=True)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out, skip=(8, 5))
     with pytest.raises(ValueError):
         ss.passive.StereoASW(maxDisparity=16, winSize=9)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out[:, :50])
+
+
+@pytest.mark.parametrize("H,W,params", [
+    (288, 384, dict(winSize=15, maxDisparity=16)),                         # Tsukuba-size: the call the shared launch is for
+    (70, 333, dict(winSize=35, maxDisparity=17, consistent=True)),         # six per lane (8-byte e slots)
+    (50, 401, dict(winSize=35, maxDisparity=100, minDisparity=3)),         # phase-shifted kernel, a width that is no multiple of 4
+    (40, 260, dict(winSize=21, maxDisparity=300)),                         # two disparity chunks of the volume
+])
+def test_lab_records_and_tad_volume_in_one_launch_equal_two(H, W, params):
+    """round 5: K0 (Lab records) and K0e (TAD volume, now read from the image bytes) share a launch when a call goes straight to
+    its cached geometry; SSAMD_ASW_PREPASS_FUSE=0 restores the two dependent launches of rounds 2-4 -- same maps, same raw costs"""
+    import torch
+    import simplestereo_amd as ss
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(H, W, min(params["maxDisparity"], W // 2), 17)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoASW(**params)
+    m.compute(tL, tR)                                   # (a first call of a shape may run the tuner's trial launches)
+    lib = _native.lib()
+    lib.ssamd_profile_enable(1); lib.ssamd_profile_reset()
+    fused = m.compute(tL, tR)
+    torch.cuda.synchronize()
+    _, n_fused = _native.profile_read()
+    with _native.options(SSAMD_ASW_PREPASS_FUSE="0"):
+        lib.ssamd_profile_reset()
+        plain = m.compute(tL, tR)
+        torch.cuda.synchronize()
+        _, n_plain = _native.profile_read()
+        sub_plain = m._compute_device(tL, tR, out_row0=5, out_rows=H - 11)
+    lib.ssamd_profile_enable(0)
+    assert torch.equal(fused, plain)
+    assert n_fused[_native.K_LAB] == 1 and n_plain[_native.K_LAB] == 2, (n_fused, n_plain)
+    # a row range of the sub-image (strips): records and volume of rows [row0 - pad, row0 + rows + pad) only
+    assert torch.equal(m._compute_device(tL, tR, out_row0=5, out_rows=H - 11), sub_plain)
+    assert torch.equal(sub_plain, fused[5:H - 6])
+    # host arrays go through the same path
+    assert np.array_equal(m.compute(L, R), fused.cpu().numpy())
