@@ -187,7 +187,16 @@ print(json.dumps({"t": dt, "kind": kind, "r0": int(r0), "cpu_s": (ru1.ru_utime -
     except AttributeError:
         navail = os.cpu_count() or 1
     visible = os.cpu_count() or 1
-    npin = max(1, min(pin_cores, navail))
+    # cgroup CPU quota of this container ("max" or "<quota> <period>" microseconds): more runnable threads than that are
+    # throttled, so the pinned sample takes at most that many cores (the GPU boxes of this pool: 16 of 256 host threads)
+    quota_cores = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota_cores = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    npin = max(1, min(pin_cores, navail, int(quota_cores) if quota_cores and quota_cores >= 1 else pin_cores))
     # The reference spawns std::thread::hardware_concurrency() threads -- on glibc 2.35 that is the number of ONLINE CPUs
     # whatever the affinity mask says (probed: taskset -c 0,1 still reports all) -- and its queue hands a row to every thread
     # that saw the queue non-empty: with fewer rows than threads the threads left over block in SafeQueue::pop for ever
@@ -231,6 +240,7 @@ print(json.dumps({"t": dt, "kind": kind, "r0": int(r0), "cpu_s": (ru1.ru_utime -
         cb["taps_per_s_per_effective_core"] = sum(r["taps"] for r in runs) / cb["cpu_s"]
         # the same rate expressed per core in the metric's unit: what ONE busy core of this host delivers
         cb["value_per_effective_core"] = cb["value"] / cb["effective_cores"]
+        cb["cgroup_quota_cores"] = quota_cores
         cb["host_loadavg_before"] = list(load0)
         cb["sample"] += "; timed %d times, value = mean, value_min / value_max = the spread" % len(runs)
         cb["map_file"] = dump
@@ -336,13 +346,18 @@ def time_matcher(matcher, tL, tR, slot, steps=3, warmup=1):
     torch.cuda.synchronize()
     once = time.perf_counter() - t0
     steps = max(steps, min(300, int(0.03 / max(once, 1e-5))))
-    lib.ssamd_profile_enable(1)
-    lib.ssamd_profile_reset()
+    # wall time WITHOUT the library's profiling events (two hipEventRecord per kernel: +10 % on a 0.12 ms Tsukuba call), then
+    # the kernel time of the same loop with them
     t0 = time.perf_counter()
     for _ in range(steps):
         out = matcher.compute(tL, tR)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps * 1e3
+    lib.ssamd_profile_enable(1)
+    lib.ssamd_profile_reset()
+    for _ in range(steps):
+        out = matcher.compute(tL, tR)
+    torch.cuda.synchronize()
     ms, launches = _native.profile_read()
     lib.ssamd_profile_enable(0)
     k_ms = ms[slot] / max(1, launches[slot]) * (launches[slot] / float(steps)) if launches[slot] else None
@@ -904,6 +919,16 @@ def main():
                     line["bad1_vs_cpu_ref"]["crop_numerical_ties_among_bad1_percent"] = 100.0 * float(np.mean((diff > 1) & tie))
                     tie6 = np.abs(cr_ - cg) <= 1e-6 * np.maximum(1.0, np.abs(cg))
                     line["bad1_vs_cpu_ref"]["crop_percent_excluding_ties_at_1e-6"] = 100.0 * float(np.mean((diff > 1) & ~tie6))
+                    # the same crop through the fp64 tie-break pass (StereoASW(exact=True)): what is left are candidates whose
+                    # fp64 costs are EQUAL to the last ulps (every tap saturated), where the reference's pick is its libm's rounding
+                    xm = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
+                                              consistent=bool(args.consistent), exact=True).compute(cl, cr)
+                    xdiff = np.abs(xm.astype(np.int32) - ref_map.astype(np.int32))
+                    line["bad1_vs_cpu_ref"]["crop_exact_mode"] = {"percent": 100.0 * float(np.mean(xdiff > 1)),
+                                                                  "exact_percent": 100.0 * float(np.mean(xdiff == 0)),
+                                                                  "pixels_changed_by_the_tie_break": int(np.count_nonzero(xm != gpu_map)),
+                                                                  "candidates_reevaluated": _native.counter("exact_entries"),
+                                                                  "queue_overflow": _native.counter("exact_overflow")}
                 except Exception as e:      # noqa: BLE001
                     line["bad1_vs_cpu_ref"]["crop_percent_excluding_numerical_ties"] = repr(e)[:120]
             except Exception as e:      # noqa: BLE001

@@ -11,9 +11,10 @@
 //   2. asw_exact_flag_kernel reads the volume once, coalesced: a candidate whose key image is within `tol` ulps of its
 //      pixel's winning key (left-referenced: keyL[y][x]; right-referenced: keyR[y][x - d]) and is not the winner itself
 //      is appended to a queue, and the pixel is flagged; asw_exact_winners_kernel appends the winners of flagged pixels;
-//   3. asw_exact_eval_kernel: one THREAD per queue entry re-evaluates that candidate's cost in fp64 with the reference's
+//   3. asw_exact_eval_kernel: one WAVE per queue entry re-evaluates that candidate's cost in fp64 with the reference's
 //      own expression and summation order (window-row-major taps, `cost += w1*w2*TAD; tot += w1*w2`, no contraction:
-//      _passive.cpp:57-88) from fp64 Lab values (colorconversion.hpp:67-69) and a proximity table built by the host's libm
+//      _passive.cpp:57-88; the tap products side by side on the lanes, the two running sums by one lane in the reference's
+//      order) from fp64 Lab values (colorconversion.hpp:67-69) and a proximity table built by the host's libm
 //      (_passive.cpp:360-364), and atomicMin's the cost's bit pattern into the pixel's slot;
 //   4. asw_exact_resolve_kernel: among the entries whose cost EQUALS the slot's minimum the smallest index wins (the
 //      reference's strict `<` scan keeps the first minimum, _passive.cpp:90-93 / 243-246);
@@ -119,53 +120,69 @@ __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactAr
     }
 }
 
-// 3. the reference's cost of one candidate, in its arithmetic (_passive.cpp:37-50, 57-88)
-__device__ __noinline__ double asw_exact_cost(const AswExactArgs &A, int y, int x, int d)
+// 3. the reference's cost of one candidate, in its arithmetic (_passive.cpp:37-50, 57-88).  One WAVE per queue entry: per
+// window row the lanes evaluate the tap products w1*w2 and w1*w2*TAD side by side (two exp, two sqrt, two divisions in fp64
+// each -- the expensive part, and independent of each other) into LDS, then lane 0 adds them to `cost` and `tot` one by one in
+// the reference's order (window-row-major, left to right): the sums round exactly as a sequential loop's would, at 1 / 50 of
+// a single thread's latency (a 35 x 35 window is 2450 dependent exp / sqrt chains: 1.1 ms for ONE entry on one lane).
+static constexpr int EXACT_WAVES = 4;          // entries in flight per workgroup
+__global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const AswExactArgs A)
 {
 #pragma clang fp contract(off)
-    const int W = A.W, H = A.H, win = A.win, p = A.pad;
-    const int xr = x - d;
-    const double *const cl = A.labL + 3 * ((size_t)y * W + x), *const cr = A.labR + 3 * ((size_t)y * W + xr);
-    const double cl0 = cl[0], cl1 = cl[1], cl2 = cl[2], cr0 = cr[0], cr1 = cr[1], cr2 = cr[2];
-    double cost = 0.0, tot = 0.0;
-    for (int i = 0; i < win; ++i) {
-        const int ii = y - p + i;
-        if (ii < 0) continue;
-        if (ii >= H) break;
-        const double *const pr = A.prox + i * win;
-        const double *const rowL = A.labL + 3 * (size_t)ii * W, *const rowR = A.labR + 3 * (size_t)ii * W;
-        const PixRec *const bL = A.recL + (size_t)ii * W, *const bR = A.recR + (size_t)ii * W;
-        for (int j = 0; j < win; ++j) {
-            const int jj = xr - p + j, kk = x - p + j;
-            if (jj < 0 || kk < 0) continue;
-            if (jj >= W || kk >= W) break;
-            const double *const tl = rowL + 3 * kk, *const tr = rowR + 3 * jj;
-            const double a0 = tl[0] - cl0, a1 = tl[1] - cl1, a2 = tl[2] - cl2;
-            const double b0 = tr[0] - cr0, b1 = tr[1] - cr1, b2 = tr[2] - cr2;
-            const double w1 = pr[j] * exp(-sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC);
-            const double w2 = pr[j] * exp(-sqrt(b0 * b0 + b1 * b1 + b2 * b2) / A.gammaC);
-            const int tad = min(40, (int)__builtin_amdgcn_sad_u8(bL[kk].bgrx, bR[jj].bgrx, 0u));
-            cost += w1 * w2 * tad;
-            tot += w1 * w2;
-        }
-    }
-    return cost / tot;
-}
-
-__global__ __launch_bounds__(64) void asw_exact_eval_kernel(const AswExactArgs A)
-{
+    __shared__ double s_w[EXACT_WAVES][256], s_c[EXACT_WAVES][256];       // (winSize <= 255)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *const sw = s_w[wv], *const sc = s_c[wv];
     const unsigned n = min(A.counter[0], A.cap);
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int W = A.W, H = A.H, win = A.win, p = A.pad;
+    for (unsigned e = blockIdx.x * EXACT_WAVES + wv; e < n; e += gridDim.x * EXACT_WAVES) {
         const u64 ent = A.entries[e];
         const uint32_t pix = (uint32_t)ent;
         const int d = (int)((ent >> 32) & 0xffff);
         const unsigned sides = (unsigned)(ent >> 48) & 3u;
-        const int yr = (int)(pix / (uint32_t)A.W), x = (int)(pix - (uint32_t)yr * (uint32_t)A.W);
-        const double c = asw_exact_cost(A, A.row0 + yr, x, d);
-        A.ecost[e] = c;
-        const u64 bits = (u64)__double_as_longlong(c);           // costs are >= 0: the bit patterns order like the values
-        if (sides & EXACT_SIDE_L) atomicMin(A.costL + pix, bits);
-        if (sides & EXACT_SIDE_R) atomicMin(A.costR + (pix - (uint32_t)d), bits);
+        const int yr = (int)(pix / (uint32_t)W), x = (int)(pix - (uint32_t)yr * (uint32_t)W);
+        const int y = A.row0 + yr, xr = x - d;
+        const double *const cl = A.labL + 3 * ((size_t)y * W + x), *const cr = A.labR + 3 * ((size_t)y * W + xr);
+        const double cl0 = cl[0], cl1 = cl[1], cl2 = cl[2], cr0 = cr[0], cr1 = cr[1], cr2 = cr[2];
+        // tap columns j with both the left column x - p + j and the right column xr - p + j inside the image (xr <= x):
+        // `continue` below 0, `break` from the width on (_passive.cpp:65-68)
+        const int jlo = max(0, p - xr), jhi = min(win, W + p - x);
+        double cost = 0.0, tot = 0.0;
+        for (int i = 0; i < win; ++i) {
+            const int ii = y - p + i;
+            if (ii < 0) continue;
+            if (ii >= H) break;
+            const double *const pr = A.prox + i * win;
+            const double *const rowL = A.labL + 3 * (size_t)ii * W, *const rowR = A.labR + 3 * (size_t)ii * W;
+            const PixRec *const bL = A.recL + (size_t)ii * W, *const bR = A.recR + (size_t)ii * W;
+            for (int j = jlo + lane; j < jhi; j += 64) {
+                const int jj = xr - p + j, kk = x - p + j;
+                const double *const tl = rowL + 3 * kk, *const tr = rowR + 3 * jj;
+                const double a0 = tl[0] - cl0, a1 = tl[1] - cl1, a2 = tl[2] - cl2;
+                const double b0 = tr[0] - cr0, b1 = tr[1] - cr1, b2 = tr[2] - cr2;
+                const double w1 = pr[j] * exp(-sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC);
+                const double w2 = pr[j] * exp(-sqrt(b0 * b0 + b1 * b1 + b2 * b2) / A.gammaC);
+                const int tad = min(40, (int)__builtin_amdgcn_sad_u8(bL[kk].bgrx, bR[jj].bgrx, 0u));
+                const double ww = w1 * w2;
+                sw[j] = ww;
+                sc[j] = ww * tad;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0)
+                for (int j = jlo; j < jhi; ++j) {
+                    cost += sc[j];
+                    tot += sw[j];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            const double c = cost / tot;
+            A.ecost[e] = c;
+            const u64 bits = (u64)__double_as_longlong(c);           // costs are >= 0: the bit patterns order like the values
+            if (sides & EXACT_SIDE_L) atomicMin(A.costL + pix, bits);
+            if (sides & EXACT_SIDE_R) atomicMin(A.costR + (pix - (uint32_t)d), bits);
+        }
     }
 }
 

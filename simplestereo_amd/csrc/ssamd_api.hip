@@ -953,7 +953,7 @@ int asw_exact_pass(Ctx &c, int H, int W, int row0, int rows, int win, int maxD, 
     hipLaunchKernelGGL(asw_exact_flag_kernel, dim3(fx, rows), dim3(256), 0, s, x);
     const int pb = (int)std::min<long long>(((long long)nout + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(asw_exact_winners_kernel, dim3(pb), dim3(256), 0, s, x);
-    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 16), dim3(64), 0, s, x);
+    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 4), dim3(64 * EXACT_WAVES), 0, s, x);
     hipLaunchKernelGGL(asw_exact_resolve_kernel, dim3(256 * 4), dim3(256), 0, s, x);
     hipLaunchKernelGGL(asw_exact_patch_kernel, dim3(pb), dim3(256), 0, s, x);
     HIP_TRY(hipGetLastError());
