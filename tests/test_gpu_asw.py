@@ -439,11 +439,11 @@ def test_asw_when_the_tad_volume_allocation_really_fails(ss):
 
 
 @pytest.mark.parametrize("shape,maxd,consistent,force", [((135, 1920), 192, False, None), ((135, 1920), 192, True, None),
-                                                         ((80, 700), 70, False, "1"), ((80, 700), 70, True, "1")])
+                                                         ((90, 700), 70, False, "1"), ((90, 700), 70, True, "1")])
 def test_asw_half_width_tiles_for_the_last_partial_round(shape, maxd, consistent, force, ss):
     """a launch whose last round of workgroups is at most half full (the 135-row strip of an 8-GPU run of config 3: 8.44
     rounds) runs the rows of that round with tiles of half the columns: same maps, same raw costs as one geometry for all rows.
-    (80 x 700 / D 0..70: 4-wave tiles of 88 columns, two resident per CU -- 640 workgroups = 1.25 rounds of 512; round 5 counts the
+    (90 x 700 / D 0..70: 4-wave tiles of 88 columns, two resident per CU -- 720 workgroups = 1.4 rounds of 512; round 5 counts the
     slots as CUs x resident workgroups, until round 4 a 37-row frame was split against 256 slots although all of it fits one round)"""
     import torch
     from simplestereo_amd.synth import make_pair
