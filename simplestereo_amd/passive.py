@@ -240,6 +240,7 @@ class StereoASW():
         if not isinstance(img1, np.ndarray) or not isinstance(img2, np.ndarray):
             raise ValueError("Invalid input format!")
         win, maxd, mind, gc, gp, cons = self._params()
+        exact = self._exact()                            # (raises for exact + alternate)
         dev = _device_index(getattr(self, "device", None))
         a, b = _check_pair(img1, img2)
         if not (win > 0 and win % 2 == 1):
@@ -248,7 +249,7 @@ class StereoASW():
         out = np.empty((H, W), np.int16)
         try:
             if devices is not None:
-                if self._exact():
+                if exact:
                     raise ValueError("exact=True is not available with devices=[...] (use row strips of device tensors: strips.py)")
                 arr, n = _device_list(devices)
                 multi = lib.ssamd_asw_alternate_multi if self._alternate(cons) else lib.ssamd_asw_multi
@@ -258,7 +259,7 @@ class StereoASW():
                 _native.check(lib.ssamd_asw_alternate(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons,
                                                       out.ctypes.data, dev))
                 return out
-            op = lib.ssamd_asw_exact if self._exact() else lib.ssamd_asw
+            op = lib.ssamd_asw_exact if exact else lib.ssamd_asw
             _native.check(op(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons, out.ctypes.data, dev))
         except _native.NativeError as e:
             _raise_native(e)
@@ -313,6 +314,7 @@ class StereoASW():
         H, W = int(a.shape[0]), int(a.shape[1])
         rows = H - out_row0 if out_rows is None else int(out_rows)
         alt = self._alternate(cons)
+        exact = self._exact()                            # (raises for exact + alternate)
         if out is None:
             out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
         elif out.dtype != torch.int16 or tuple(out.shape) != (rows, W) or not out.is_contiguous() or out.device != a.device:
@@ -321,7 +323,7 @@ class StereoASW():
             stream = torch.cuda.current_stream(a.device).cuda_stream
             try:
                 if skip is not None and skip[1] > 0:
-                    if alt or self._exact():
+                    if alt or exact:
                         raise ValueError("two row ranges: not with alternate=True / exact=True")
                     _native.check(lib.ssamd_asw_device_rows2(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, int(skip[0]), int(skip[1]),
                                                              win, maxd, mind, gc, gp, cons, out.data_ptr(), ctypes.c_void_p(stream)))
@@ -331,7 +333,7 @@ class StereoASW():
                                                                       int(row_parity) & 1, win, maxd, mind, gc, gp, cons,
                                                                       out.data_ptr(), ctypes.c_void_p(stream)))
                     return out
-                op = lib.ssamd_asw_exact_device if self._exact() else lib.ssamd_asw_device
+                op = lib.ssamd_asw_exact_device if exact else lib.ssamd_asw_device
                 _native.check(op(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win, maxd, mind, gc, gp, cons, out.data_ptr(),
                                  ctypes.c_void_p(stream)))
             except _native.NativeError as e:
