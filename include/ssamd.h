@@ -226,6 +226,11 @@ int ssamd_asw_argmins(const uint8_t *img1, const uint8_t *img2, int height, int 
  * headers/colorconversion.hpp:81-86); float32 [height][width][3]. Host buffers. */
 int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int device);
 
+/* The device's restatements of the two libm functions the reference's ASW path calls (csrc/glibc_math.hip.h), evaluated on n HOST
+ * values: which = 0: exp on doubles (reference _passive.cpp:47-50); which = 1: powf(x, (float)(1/3.0)) on floats
+ * (headers/colorconversion.hpp:55-65).  Lets a test prove them equal to the host's libm bit for bit. */
+int ssamd_debug_libm(int which, int n, const void *in, void *out);
+
 /* The GSW kernels' exact integer square root, evaluated on the device for s = 0 .. n-1 (n <= 195076)
  * into a HOST buffer: lets a test prove it equals (float)sqrt((double)s) over the whole domain. */
 int ssamd_debug_gsw_sqrt(int n, float *out);

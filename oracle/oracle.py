@@ -27,7 +27,7 @@ def build(force=False):
     """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
     if force or not os.path.exists(_LIB) or \
             os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "oracle_passive.c")):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_passive.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_passive.so", "libm_check"])
     if os.path.exists("/root/reference/simplestereo/_passive.cpp") and (
             force or ref_module() is None or not os.path.exists(os.path.join(_HERE, "_ref", "libref_lab.so"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])

@@ -98,6 +98,8 @@ def lib():
     L.ssamd_remap_bgr_device.argtypes = [P, I, I, P, P, I, I, I, P, P]
     L.ssamd_reproject_device.restype = I
     L.ssamd_reproject_device.argtypes = [P, I, I, ctypes.POINTER(D), P, P]
+    L.ssamd_debug_libm.restype = I
+    L.ssamd_debug_libm.argtypes = [I, I, P, P]
     L.ssamd_debug_gsw_sqrt.restype = I
     L.ssamd_debug_gsw_sqrt.argtypes = [I, P]
     L.ssamd_profile_enable.restype = I

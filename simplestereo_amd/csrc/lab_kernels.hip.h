@@ -3,6 +3,7 @@
 // (reference headers/colorconversion.hpp:18-86, called at _passive.cpp:337-341).
 #pragma once
 #include "common.hip.h"
+#include "glibc_math.hip.h"
 
 namespace ssamd {
 
@@ -10,14 +11,14 @@ namespace ssamd {
 // depends on the byte, so it is a 256-entry table filled once by the host.
 __constant__ float c_lin100[256];
 
-// CIE f(t) with the reference's precision mix: float powf above the knee, double
-// linear segment below (colorconversion.hpp:55-65).
-// powf(t, (float)(1 / 3.0)) for t in (0.008856, ~1.1] as the correctly rounded float (up to double-rounding ties) of the
-// real power: the device library's powf spends ~150 instructions per call on a general (x, y) -- 80 % of this kernel --
-// while a cube root needs a handful.  z = t^(-1/3) by division-free Newton steps from a v_log / v_exp seed, one in fp32 and
-// one in fp64 (1e-6 -> 1e-7 -> 1e-14), c = t z^2 = t^(1/3), and the exponent's distance from 1/3, dy = (float)(1/3.0) - 1/3 =
-// 9.93e-9, enters as t^dy = 1 + dy ln t (next term 1e-16).  The reference's glibc powf is within 0.82 ulp of the same real.
-#ifndef SSAMD_LAB_LIBM_POWF
+// CIE f(t) with the reference's precision mix: float powf above the knee, double linear segment below
+// (colorconversion.hpp:55-65).  Round 5: powf is glibc's own algorithm restated (glibc_math.hip.h: table-driven log2 / exp2 in
+// double, one rounding to float) and returns the SAME float as the libm the reference links for every argument the conversion can
+// produce -- checked exhaustively on the host (oracle/libm_check.c) -- so the records hold exactly the reference's Lab values
+// rounded to float, and the fp64 tie-break pass the reference's doubles.  (Rounds 2-4 computed a correctly rounded cube root by
+// Newton steps: 99.90 % of the floats were glibc's, whose powf is within 0.82 ulp but not correctly rounded.  -DSSAMD_LAB_NEWTON
+// keeps that form for A/B builds.)
+#ifdef SSAMD_LAB_NEWTON
 __device__ __forceinline__ float lab_pow_third(float tf)
 {
     const double t = (double)tf;
@@ -34,11 +35,12 @@ __device__ __forceinline__ float lab_pow_third(float tf)
     return (float)fma(c * dy, (double)(l2 * 0.6931471805599453f), c);
 }
 #else
-__device__ __forceinline__ float lab_pow_third(float tf) { return powf(tf, (float)(1 / 3.0)); }
+__device__ __forceinline__ float lab_pow_third(float tf) { return glibc_powf_pos(tf, (float)(1 / 3.0)); }
 #endif
 
 __device__ __forceinline__ double lab_f(double t)
 {
+#pragma clang fp contract(off)
     if (t > 0.008856) return (double)lab_pow_third((float)t);
     return (7.787 * t) + (16.0 / 116.0);
 }
@@ -47,6 +49,7 @@ __device__ __forceinline__ double lab_f(double t)
 // the aggregation kernels use them rounded to float, the fp64 tie-break pass (asw_exact_kernels.hip.h) as they are.
 __device__ __forceinline__ void bgr_to_lab_f64(uint32_t B, uint32_t G, uint32_t R, double &L, double &a, double &b)
 {
+#pragma clang fp contract(off)           // (the reference is a plain x86-64 build: no fused multiply-adds in its matrix and affine steps)
     const float r = c_lin100[R], g = c_lin100[G], bl = c_lin100[B];
     // observer 2 deg / D65 matrix in fp64 (colorconversion.hpp:40-42)
     const double X = r * 0.4124 + g * 0.3576 + bl * 0.1805;

@@ -2274,6 +2274,34 @@ int ssamd_reproject_device(const int16_t *d_disparity, int h, int w, const doubl
     return SSAMD_OK;
 }
 
+namespace {
+__global__ void debug_libm_kernel(int which, int n, const void *in, void *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) reinterpret_cast<double *>(out)[i] = glibc_exp(reinterpret_cast<const double *>(in)[i]);
+    else reinterpret_cast<float *>(out)[i] = ssamd::lab_pow_third(reinterpret_cast<const float *>(in)[i]);
+}
+}  // namespace
+
+int ssamd_debug_libm(int which, int n, const void *in, void *out)
+{
+    if (!in || !out || n < 0 || (which != 0 && which != 1)) return fail(SSAMD_EINVAL, "ssamd_debug_libm: which = 0 (exp, doubles) or 1 (powf(x, 1/3), floats)");
+    if (n == 0) return SSAMD_OK;
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n * (which == 0 ? 8 : 4);
+    if ((rc = c->lab.reserve(2 * bytes))) return rc;
+    char *const d_in = (char *)c->lab.ptr, *const d_out = d_in + bytes;
+    HIP_TRY(hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(debug_libm_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, which, n, (const void *)d_in, (void *)d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSAMD_OK;
+}
+
 int ssamd_debug_gsw_sqrt(int n, float *out)
 {
     int what = 0;

@@ -206,3 +206,15 @@ def test_full_frame_golden_rows_reproduced_by_the_restatement():
         pad, r0, rows = g["winSize"] // 2, 300, 40
         band = oracle.gsw(np.ascontiguousarray(L[r0 - pad:r0 + rows + pad]), np.ascontiguousarray(R[r0 - pad:r0 + rows + pad]), closed=True, **g)
         assert np.array_equal(band[pad:pad + rows], maps["F4"][r0:r0 + rows])
+
+
+def test_device_libm_restatement_equals_this_libm():
+    """simplestereo_amd/csrc/glibc_math.hip.h (glibc's exp and powf as the device runs them: tables of
+    tools/extract_glibc_tables.py, the FMA build's fused steps) compiled as plain C against the libm of this process:
+    oracle/libm_check.c -- exp on 8 million arguments incl. the rescaled and special branches, powf(x, 1/3) on every float
+    of [0.008856, 1.3].  Bit-identical or the fp64 tie-break pass cannot reproduce the reference's saturated ties."""
+    import subprocess
+    odir = os.path.join(os.path.dirname(GOLDEN), "..", "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir, "libm_check"])
+    r = subprocess.run([os.path.join(odir, "libm_check"), "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "libm_check ok" in r.stdout, r.stdout[-2000:]
