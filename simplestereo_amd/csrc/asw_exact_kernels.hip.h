@@ -66,6 +66,7 @@ __device__ __forceinline__ u64 exact_entry(uint32_t pix, int d, unsigned sides)
 __global__ __launch_bounds__(256) void bgr2lab_f64_pair_kernel(const PixRec *__restrict__ recL, const PixRec *__restrict__ recR,
                                                                double *__restrict__ labL, double *__restrict__ labR, long long npix)
 {
+    SSAMD_LAB_TABLES_IN_LDS(T)
     long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; q < 2 * npix; q += stride) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void bgr2lab_f64_pair_kernel(const PixRec *__r
         const long long p = right ? q - npix : q;
         const uint32_t v = (right ? recR : recL)[p].bgrx;
         double L, a, b;
-        bgr_to_lab_f64(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, L, a, b);
+        bgr_to_lab_f64(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, L, a, b, T);
         double *const o = (right ? labR : labL) + 3 * p;
         o[0] = L; o[1] = a; o[2] = b;
     }

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void asw_prepass_kernel(const AswPrepassArgs P
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < P.lab_blocks) {
+        SSAMD_LAB_TABLES_IN_LDS(T)
         const long long np = (long long)P.erows * P.W, first = (long long)P.erow0 * P.W;
         const uint8_t *const bl = P.bgrL + 3 * first, *const br = P.bgrR + 3 * first;
         PixRec *const rl = P.recL + first, *const rr = P.recR + first;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void asw_prepass_kernel(const AswPrepassArgs P
                 B = bgr[3 * p]; G = bgr[3 * p + 1]; R = bgr[3 * p + 2];
             }
             PixRec o;
-            bgr_to_lab(B, G, R, o.L, o.a, o.b);
+            bgr_to_lab(B, G, R, o.L, o.a, o.b, T);
             o.bgrx = B | (G << 8) | (R << 16);
             (right ? rr : rl)[p] = o;
         }

@@ -99,7 +99,9 @@ GM_FN double glibc_exp(double x)
 
 // glibc powf(x, y) for normal positive x and finite y whose result neither overflows nor underflows (e_powf.c: log2_inline,
 // exp2_inline, sign_bias 0) -- the Lab conversion calls it with x in (0.008856, ~1.1] and y = (float)(1 / 3.0).
-GM_FN float glibc_powf_pos(float x, float y)
+// (log2tab / exp2tab: the two tables, in whatever memory the caller staged them -- the Lab kernels keep them in LDS: per-lane
+//  indices into constant memory cost three dependent global loads per call, 58 -> 207 us for both 4096 x 2160 images)
+GM_FN float glibc_powf_pos_t(float x, float y, const double *log2tab, const uint64_t *exp2tab)
 {
     GM_CONTRACT_OFF
     const uint32_t ix = gm_asu32(x);
@@ -108,7 +110,7 @@ GM_FN float glibc_powf_pos(float x, float y)
     const uint32_t top = tmp & 0xff800000u;
     const uint32_t iz = ix - top;
     const int k = (int32_t)top >> 23;                                // arithmetic shift
-    const double invc = gm_powf_log2_tab[2 * i], logc = gm_powf_log2_tab[2 * i + 1];
+    const double invc = log2tab[2 * i], logc = log2tab[2 * i + 1];
     const double z = (double)gm_asf32(iz);
     const double r = fma(z, invc, -1.0), y0 = logc + (double)k;
     const double r2 = r * r;
@@ -123,7 +125,7 @@ GM_FN float glibc_powf_pos(float x, float y)
     const uint64_t ki = gm_asu64(kd);
     kd -= GLIBC_EXP2F_SHIFT_SCALED;                                  // k / 32
     const double rr = ylogx - kd;
-    uint64_t t = gm_exp2f_tab[ki % 32];
+    uint64_t t = exp2tab[ki % 32];
     t += ki << (52 - 5);
     const double s = gm_asf64(t);
     const double zz = fma(GLIBC_EXP2F_C0, rr, GLIBC_EXP2F_C1), rr2 = rr * rr;
@@ -131,3 +133,5 @@ GM_FN float glibc_powf_pos(float x, float y)
     yv = fma(zz, rr2, yv);
     return (float)(yv * s);
 }
+
+GM_FN float glibc_powf_pos(float x, float y) { return glibc_powf_pos_t(x, y, gm_powf_log2_tab, gm_exp2f_tab); }

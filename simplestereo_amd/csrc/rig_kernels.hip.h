@@ -99,6 +99,7 @@ struct RemapSrc {
 __global__ __launch_bounds__(256) void remap_lab_records_pair_kernel(const RemapSrc S, PixRec *__restrict__ recL, PixRec *__restrict__ recR,
                                                                      long long pix0, long long npix)
 {
+    SSAMD_LAB_TABLES_IN_LDS(T)
     const size_t src_bytes = (size_t)S.Hs * S.Ws * 3;
     long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void remap_lab_records_pair_kernel(const Remap
         const uint32_t v = remap_pixel(right ? S.src2 : S.src1, S.Hs, S.Ws, src_bytes, (right ? S.mapx2 : S.mapx1)[p],
                                        (right ? S.mapy2 : S.mapy1)[p], S.nearest);
         PixRec o;
-        bgr_to_lab(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, o.L, o.a, o.b);
+        bgr_to_lab(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff, o.L, o.a, o.b, T);
         o.bgrx = v;
         (right ? recR : recL)[p] = o;
     }

@@ -2280,7 +2280,7 @@ __global__ void debug_libm_kernel(int which, int n, const void *in, void *out)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (which == 0) reinterpret_cast<double *>(out)[i] = glibc_exp(reinterpret_cast<const double *>(in)[i]);
-    else reinterpret_cast<float *>(out)[i] = ssamd::lab_pow_third(reinterpret_cast<const float *>(in)[i]);
+    else reinterpret_cast<float *>(out)[i] = glibc_powf_pos(reinterpret_cast<const float *>(in)[i], (float)(1 / 3.0));
 }
 }  // namespace
 
