@@ -384,12 +384,15 @@ def others(dev, seed):
             ("c2_480p_d64_w35", "c2_480p_d64_w35", False),
             ("default_1080p_d16_w35", "default_1080p_d16_w35", False), ("small_1080p_d7_w35", "small_1080p_d7_w35", False),
             ("c5_4k_d256_w35_1gpu", "c5_4k_d256_w35", False)]
+    jobs += [("c3_1080p_d192_w35_exact", "c3_1080p_d192_w35", "exact"), ("c3_1080p_d192_w35_consistent_exact", "c3_1080p_d192_w35", "exact+consistent")]
     for name, cfgname, consistent in jobs:
         try:
             H, W, maxD, minD, win = CONFIGS[cfgname]
             tL, tR = pair(H, W, maxD)
+            exact = isinstance(consistent, str)           # opt-in fp64 tie-break pass: the reference's map bit for bit
+            consistent = consistent is True or consistent == "exact+consistent"
             m = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
-                                     consistent=consistent)
+                                     consistent=consistent, exact=exact)
             wall, k_ms, checksum = time_matcher(m, tL, tR, _native.K_ASW_AGG)
             taps = count_taps(H, W, win, maxD, minD)
             nD = maxD - minD + 1
@@ -402,8 +405,14 @@ def others(dev, seed):
                          # share of the work for small disparity ranges, ~1.5 % at D 0..192
                          "weight_lane_ops": wops,
                          "valu_frac_with_weights": (VALU_OPS_PER_TAP * taps + wops) / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None,
-                         "issue": replayed_issue(cfgname, k_ms) if not consistent else None,
+                         "issue": replayed_issue(cfgname, k_ms) if not (consistent or exact) else None,
                          "kernel_form": _native.asw_kernel_form(W, H, win, maxD, minD)}
+            if exact:
+                res[name].update({"exact": True, "candidates_reevaluated": _native.counter("exact_entries"),
+                                  "pixels_flagged": [_native.counter("exact_flagged_left"), _native.counter("exact_flagged_right")],
+                                  "queue_overflow": _native.counter("exact_overflow"),
+                                  "note": "StereoASW(exact=True): kernel_ms is the aggregation kernel WITH its cost-image dump; ms_per_step "
+                                          "includes the fp64 pass; the map against the reference: bad1_vs_cpu_ref.exact_mode"})
         except Exception as e:      # noqa: BLE001
             res[name] = {"error": repr(e)[:200]}
     for name, (H, W, maxD, minD, win) in GSW_CONFIGS.items():
@@ -497,10 +506,27 @@ def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
                       "consistent": bool(p.get("consistent", True if gsw else False)), "maxDisparity": p["maxDisparity"],
                       "minDisparity": p["minDisparity"], "recipe": what}
     through = "one launch per case" if world == 1 else "StripContext over %d ranks (row strips, RCCL halo exchange, all_gather)" % world
+    exact_mode = None
+    if head in cases and world == 1:
+        # the same frame through the opt-in fp64 tie-break pass (StereoASW(exact=True)): the reference's map itself
+        try:
+            m = fmeta[head]
+            p = {k: v for k, v in m["params"].items() if k != "algo"}
+            a, b = frames[tuple(m["frame"])]
+            d = ss.passive.StereoASW(exact=True, **p).compute(a, b)
+            diff = np.abs(d.astype(np.int32) - fmaps[head].astype(np.int32))
+            from simplestereo_amd import _native
+            exact_mode = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
+                          "differing_pixels": int(np.count_nonzero(diff)), "pixels": int(diff.size),
+                          "candidates_reevaluated": _native.counter("exact_entries"), "queue_overflow": _native.counter("exact_overflow"),
+                          "what": "StereoASW(exact=True) on the whole bench frame against the same reference map (%s)" % head}
+        except Exception as e:      # noqa: BLE001
+            exact_mode = {"error": repr(e)[:200]}
     if head in cases:
         h = cases[head]
         return {"percent": h["percent"], "exact_percent": h["exact_percent"], "pixels": h["pixels"], "bad1_pixels": h["bad1_pixels"],
-                "differing_pixels": h["differing_pixels"], "headline_case": head, "tie_exclusion": "none", "cases": cases, "through": through,
+                "differing_pixels": h["differing_pixels"], "headline_case": head, "tie_exclusion": "none", "exact_mode": exact_mode,
+                "cases": cases, "through": through,
                 "source": "tests/golden/full_cases.npz %s: the WHOLE frame of this run (make_pair(1080,1920,192,seed=1), D 0..192, win 35, "
                           "consistent=%s) through the unmodified reference (_passive.cpp via oracle/_ref, "
                           "tests/golden/make_golden_full.py), every pixel counted; cases: the other full-frame maps (F3c/F3p, "

@@ -163,3 +163,5 @@ def test_bench_line_carries_the_contract_keys():
     assert line["speedup_per_effective_core"] > line["speedup_vs_cpu_baseline"] > 0
     b = line["bad1_vs_cpu_ref"]
     assert b["percent"] <= 0.5 and b["pixels"] == 1080 * 1920 and b["headline_case"] == "F3p" and b["exact_percent"] >= 99.0
+    # ... and the same frame through StereoASW(exact=True): the reference's map itself
+    assert b["exact_mode"]["differing_pixels"] == 0 and b["exact_mode"]["pixels"] == 1080 * 1920 and b["exact_mode"]["queue_overflow"] == 0
