@@ -231,6 +231,11 @@ int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int dev
  * (headers/colorconversion.hpp:55-65).  Lets a test prove them equal to the host's libm bit for bit. */
 int ssamd_debug_libm(int which, int n, const void *in, void *out);
 
+/* The fp64 cost the tie-break pass computes for each of n candidates (yxd: n triples y, x, d of HOST ints) of a host image pair, and
+ * optionally (non-NULL) the fp64 CIELab images [height][width][3] it reads: lets a test compare them with the oracle's bit for bit. */
+int ssamd_debug_exact_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, double gammaC, double gammaP,
+                            int n, const int *yxd, double *costs, double *lab1, double *lab2);
+
 /* The GSW kernels' exact integer square root, evaluated on the device for s = 0 .. n-1 (n <= 195076)
  * into a HOST buffer: lets a test prove it equals (float)sqrt((double)s) over the whole domain. */
 int ssamd_debug_gsw_sqrt(int n, float *out);

@@ -100,6 +100,8 @@ def lib():
     L.ssamd_reproject_device.argtypes = [P, I, I, ctypes.POINTER(D), P, P]
     L.ssamd_debug_libm.restype = I
     L.ssamd_debug_libm.argtypes = [I, I, P, P]
+    L.ssamd_debug_exact_costs.restype = I
+    L.ssamd_debug_exact_costs.argtypes = [P, P, I, I, I, D, D, I, P, P, P, P]
     L.ssamd_debug_gsw_sqrt.restype = I
     L.ssamd_debug_gsw_sqrt.argtypes = [I, P]
     L.ssamd_profile_enable.restype = I

@@ -49,13 +49,38 @@ struct AswExactArgs {
     uint32_t *idxL, *idxR;           // [rows][W] smallest index among the entries at that minimum
     int H, W, win, pad, minD, maxD, row0, rows;
     uint32_t tol;                    // key ulps
+    float sat_abs;                   // absolute cost difference below which two saturated candidates are a near-tie of the reference's fp64
     double gammaC;
 };
 
+// sqrt as the host computes it (IEEE, correctly rounded): the device's f64 square root (v_rsq_f64 + Goldschmidt steps) is within an
+// ulp but not always the correctly rounded one; with the exact residual e = x - y0^2 (one fma) the root is y0 + e / (2 y0) up to
+// a relative 1e-32, and that sum rounds correctly unless it falls within 1e-16 ulp of a rounding boundary.
+__device__ __forceinline__ double exact_sqrt(double x)
+{
+#pragma clang fp contract(off)
+    const double y0 = sqrt(x);
+    if (!(y0 > 0.0) || !(y0 < 1.0e300)) return y0;                   // 0, nan, inf
+    const double e = fma(-y0, y0, x);
+    return y0 + e / (2.0 * y0);
+}
+
 static constexpr unsigned EXACT_SIDE_L = 1u, EXACT_SIDE_R = 2u;
-// cost image (asw_cost_key) of 40 - 2e-13: candidates at or above it are equal to the reference's fp64 arithmetic up to its own
-// rounding noise (a sum of <= 65025 products of relative error 1.1e-16 each; the cap is 40)
-static constexpr uint32_t EXACT_KEY_SAT = 0xC0000000u - 0x2A612E13u;      // 0x2A612E13 = bits of 2.0e-13f
+// cost images (asw_cost_key) at or above this hold 40 - cost (cost > 20)
+static constexpr uint32_t EXACT_KEY_HIGH = 0xC0000000u - 0x41A00000u;      // 0x41A00000 = bits of 20.0f
+
+// is candidate image `key` a near-tie of the winning image `kb` (kb <= key)?
+__device__ __forceinline__ bool exact_near(uint32_t key, uint32_t kb, uint32_t tol, float sat_abs)
+{
+    if (key - kb <= tol) return true;
+    if (key >= EXACT_KEY_HIGH) {
+        const float inv = __uint_as_float(0xC0000000u - key);                                   // 40 - cost of the candidate
+        if (kb >= EXACT_KEY_HIGH) return __uint_as_float(0xC0000000u - kb) - inv <= sat_abs;
+        // the two images lie either side of cost = 20 (the winner's holds its cost, the candidate's 40 - cost): ulps do not compare
+        return (40.0f - inv) - __uint_as_float(kb) <= 20.0f * 1.1920929e-7f * (float)tol;
+    }
+    return false;
+}
 
 __device__ __forceinline__ u64 exact_entry(uint32_t pix, int d, unsigned sides)
 {
@@ -93,20 +118,15 @@ __global__ __launch_bounds__(256) void asw_exact_flag_kernel(const AswExactArgs 
         if (x - d < 0) continue;                                   // not a candidate the reference evaluates (_passive.cpp:56)
         const uint32_t key = krow[e];
         unsigned sides = 0;
-        // near-tie: within `tol` ulps of the winner's cost image -- or BOTH within 2e-13 of the cap 40 (images >= EXACT_KEY_SAT): the
-        // (N, S') pair tells 40 - 1e-30 from 40 - 0, the reference's fp64 quotient does not (both round to 40 (1 - k ulp)), and its
-        // first minimum among such candidates is what the pass has to find
+        // near-tie: within `tol` ulps of the winner's cost image -- or, on the saturated side of the image (cost > 20: the image
+        // holds 40 - cost), within `sat_abs` of it in ABSOLUTE terms: the (N, S') pair resolves 40 - 1e-30 from 40 - 0, but the
+        // reference's fp64 quotient carries a rounding noise of up to ~(win^2) ulps of 40 (2e-11 for a 35 x 35 window), so among
+        // candidates closer than that its first minimum is decided by that noise and has to be recomputed
         const u64 bl = kl[x];
-        if (bl != KEY_NONE && (int)(uint32_t)bl != d) {
-            const uint32_t kb = (uint32_t)(bl >> 32);
-            if (key - kb <= A.tol || (key >= EXACT_KEY_SAT && kb >= EXACT_KEY_SAT)) sides |= EXACT_SIDE_L;
-        }
+        if (bl != KEY_NONE && (int)(uint32_t)bl != d && exact_near(key, (uint32_t)(bl >> 32), A.tol, A.sat_abs)) sides |= EXACT_SIDE_L;
         if (kr) {
             const u64 br = kr[x - d];
-            if (br != KEY_NONE && (int)(uint32_t)br != x) {
-                const uint32_t kb = (uint32_t)(br >> 32);
-                if (key - kb <= A.tol || (key >= EXACT_KEY_SAT && kb >= EXACT_KEY_SAT)) sides |= EXACT_SIDE_R;
-            }
+            if (br != KEY_NONE && (int)(uint32_t)br != x && exact_near(key, (uint32_t)(br >> 32), A.tol, A.sat_abs)) sides |= EXACT_SIDE_R;
         }
         if (!sides) continue;
         const uint32_t pix = (uint32_t)yr * (uint32_t)A.W + (uint32_t)x;
@@ -175,8 +195,8 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
                 const double *const tl = rowL + 3 * kk, *const tr = rowR + 3 * jj;
                 const double a0 = tl[0] - cl0, a1 = tl[1] - cl1, a2 = tl[2] - cl2;
                 const double b0 = tr[0] - cr0, b1 = tr[1] - cr1, b2 = tr[2] - cr2;
-                const double w1 = pr[j] * glibc_exp(-sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC);
-                const double w2 = pr[j] * glibc_exp(-sqrt(b0 * b0 + b1 * b1 + b2 * b2) / A.gammaC);
+                const double w1 = pr[j] * glibc_exp(-exact_sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC);
+                const double w2 = pr[j] * glibc_exp(-exact_sqrt(b0 * b0 + b1 * b1 + b2 * b2) / A.gammaC);
                 const int tad = min(40, (int)__builtin_amdgcn_sad_u8(bL[kk].bgrx, bR[jj].bgrx, 0u));
                 const double ww = w1 * w2;
                 sw[j] = ww;

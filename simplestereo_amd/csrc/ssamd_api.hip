@@ -938,7 +938,13 @@ int asw_exact_pass(Ctx &c, int H, int W, int row0, int rows, int win, int maxD, 
     x.costL = (u64 *)c.xslots.ptr; x.costR = x.costL + nout;
     x.idxL = (uint32_t *)(x.costR + nout); x.idxR = x.idxL + nout;
     x.H = H; x.W = W; x.win = win; x.pad = p; x.minD = minD; x.maxD = maxD; x.row0 = row0; x.rows = rows;
-    x.tol = (uint32_t)tune().exact_tol;
+    // 128 ulps = 1.5e-5 relative at gammaC = 5: the kernels' support weights inherit the rounding of the Lab records to float
+    // (|dLab| <= ~1.3e-5 per colour distance), i.e. a relative error of ~2.6e-5 / gammaC on a weight product -- scaled up for smaller gammaC
+    x.tol = (uint32_t)std::min(1.0e6, (double)tune().exact_tol * std::max(1.0, 5.0 / gammaC));
+    // rounding noise of the reference's fp64 quotient sum(w e) / sum(w) over n = win^2 taps: <= ~(n + 3) u relative on numerator and
+    // denominator each, u = 2^-53, i.e. 2 (n + 3) u 40 absolute near the cap; two candidates can swap places when they are
+    // closer than twice that (x 1.5 margin)
+    x.sat_abs = (float)(1.5 * 2.0 * 2.0 * ((double)win * win + 3.0) * 1.1102230246251565e-16 * 40.0);
     x.gammaC = gammaC;
     Timed t(c, s, SSAMD_K_ASW_EXACT);
     {
@@ -2182,6 +2188,57 @@ int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int dev
     return SSAMD_OK;
 }
 
+// Verification: the fp64 costs the tie-break pass computes for n given candidates (y, x, d triples), and optionally the fp64 Lab
+// images it reads -- to compare with the oracle's fp64 costs bit for bit.
+int ssamd_debug_exact_costs(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, double gammaC, double gammaP,
+                            int n, const int *yxd, double *costs, double *lab1, double *lab2)
+{
+    if (!img1 || !img2 || !yxd || !costs || n < 0) return fail(SSAMD_EINVAL, "NULL buffer");
+    int rc = check_common(height, width, winSize, 0, 0, 0, height);
+    if (rc) return rc;
+    CtxLock c;
+    if ((rc = get_ctx(-1, c))) return rc;
+    const size_t npix = (size_t)height * width;
+    hipStream_t s = c->stream;
+    ScratchOrder order(*c, s);
+    if ((rc = c->imgL.reserve(npix * 3)) || (rc = c->imgR.reserve(npix * 3)) || (rc = c->recL.reserve(npix * sizeof(PixRec))) ||
+        (rc = c->recR.reserve(npix * sizeof(PixRec))) || (rc = c->xlabL.reserve(npix * 24)) || (rc = c->xlabR.reserve(npix * 24)) ||
+        (rc = c->xqueue.reserve((size_t)std::max(n, 1) * 8)) || (rc = c->xcost.reserve((size_t)std::max(n, 1) * 8)) || (rc = c->xctr.reserve(64)))
+        return rc;
+    c->xcap = (unsigned int)std::max(n, 1);
+    HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img1, npix * 3, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, npix * 3, hipMemcpyHostToDevice, s));
+    const int blocks = (int)std::min<long long>((2 * (long long)npix + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(bgr2lab_records_pair_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t *)c->imgL.ptr, (const uint8_t *)c->imgR.ptr,
+                       (PixRec *)c->recL.ptr, (PixRec *)c->recR.ptr, (long long)npix);
+    hipLaunchKernelGGL(bgr2lab_f64_pair_kernel, dim3(blocks), dim3(256), 0, s, (const PixRec *)c->recL.ptr, (const PixRec *)c->recR.ptr,
+                       (double *)c->xlabL.ptr, (double *)c->xlabR.ptr, (long long)npix);
+    std::vector<u64> ent((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const int y = yxd[3 * k], x = yxd[3 * k + 1], d = yxd[3 * k + 2];
+        if (y < 0 || y >= height || x < 0 || x >= width || d < 0 || x - d < 0) return fail(SSAMD_EINVAL, "candidate %d outside the image", k);
+        ent[k] = (u64)((uint32_t)y * (uint32_t)width + (uint32_t)x) | ((u64)(uint32_t)d << 32);       // sides = 0: cost only
+    }
+    const unsigned int ctr[4] = {(unsigned int)n, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(c->xqueue.ptr, ent.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->xctr.ptr, ctr, sizeof(ctr), hipMemcpyHostToDevice, s));
+    const double *d_prox = nullptr;
+    if ((rc = get_prox64(*c, winSize, gammaP, s, &d_prox))) return rc;
+    AswExactArgs x{};
+    x.recL = (const PixRec *)c->recL.ptr; x.recR = (const PixRec *)c->recR.ptr;
+    x.labL = (const double *)c->xlabL.ptr; x.labR = (const double *)c->xlabR.ptr;
+    x.prox = d_prox; x.entries = (u64 *)c->xqueue.ptr; x.counter = (unsigned int *)c->xctr.ptr; x.cap = (unsigned int)std::max(n, 1);
+    x.ecost = (double *)c->xcost.ptr;
+    x.H = height; x.W = width; x.win = winSize; x.pad = winSize / 2; x.row0 = 0; x.rows = height; x.gammaC = gammaC;
+    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256), dim3(64 * EXACT_WAVES), 0, s, x);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(costs, c->xcost.ptr, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (lab1) HIP_TRY(hipMemcpyAsync(lab1, c->xlabL.ptr, npix * 24, hipMemcpyDeviceToHost, s));
+    if (lab2) HIP_TRY(hipMemcpyAsync(lab2, c->xlabR.ptr, npix * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SSAMD_OK;
+}
+
 int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
                      int winSize, int maxDisparity, int minDisparity, int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream)
@@ -2280,18 +2337,21 @@ __global__ void debug_libm_kernel(int which, int n, const void *in, void *out)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (which == 0) reinterpret_cast<double *>(out)[i] = glibc_exp(reinterpret_cast<const double *>(in)[i]);
-    else reinterpret_cast<float *>(out)[i] = glibc_powf_pos(reinterpret_cast<const float *>(in)[i], (float)(1 / 3.0));
+    else if (which == 1) reinterpret_cast<float *>(out)[i] = glibc_powf_pos(reinterpret_cast<const float *>(in)[i], (float)(1 / 3.0));
+    else if (which == 2) reinterpret_cast<double *>(out)[i] = ssamd::exact_sqrt(reinterpret_cast<const double *>(in)[i]);
+    else reinterpret_cast<double *>(out)[i] = reinterpret_cast<const double *>(in)[i] / 0.7 + reinterpret_cast<const double *>(in)[i] / 5.0;
 }
 }  // namespace
 
 int ssamd_debug_libm(int which, int n, const void *in, void *out)
 {
-    if (!in || !out || n < 0 || (which != 0 && which != 1)) return fail(SSAMD_EINVAL, "ssamd_debug_libm: which = 0 (exp, doubles) or 1 (powf(x, 1/3), floats)");
+    if (!in || !out || n < 0 || which < 0 || which > 3)
+        return fail(SSAMD_EINVAL, "ssamd_debug_libm: which = 0 (exp, doubles), 1 (powf(x, 1/3), floats), 2 (sqrt, doubles), 3 (x / 0.7 + x / 5.0, doubles)");
     if (n == 0) return SSAMD_OK;
     CtxLock c;
     int rc = get_ctx(-1, c);
     if (rc) return rc;
-    const size_t bytes = (size_t)n * (which == 0 ? 8 : 4);
+    const size_t bytes = (size_t)n * (which == 1 ? 4 : 8);
     if ((rc = c->lab.reserve(2 * bytes))) return rc;
     char *const d_in = (char *)c->lab.ptr, *const d_out = d_in + bytes;
     HIP_TRY(hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream));

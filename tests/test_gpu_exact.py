@@ -226,3 +226,68 @@ def test_exact_mode_full_bench_frame_is_the_references_map():
         n = int(np.count_nonzero(d != maps[cid]))
         print("%s exact: %d of %d pixels differ from the reference" % (cid, n, d.size))
         assert n == 0, (cid, n)
+
+
+def test_exact_pass_costs_and_lab_are_the_oracles_bits():
+    """ssamd_debug_exact_costs: the fp64 cost the tie-break pass computes for random candidates, and the fp64 Lab images it
+    reads, against the C restatement's (bit-exact with the reference on every golden) -- every bit, flat / saturated content and
+    extreme gammas included; and the device's corrected sqrt and its division against the host's"""
+    from oracle import oracle
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    rng = np.random.default_rng(11)
+    for (H, W, win, maxd, gc, gp, flat) in [(10, 221, 35, 56, 5.0, 17.5, True), (53, 66, 21, 39, 0.7, 17.5, True), (30, 120, 9, 30, 5.0, 17.5, False),
+                                             (5, 199, 21, 50, 0.7, 3.0, False)]:
+        L, R, _ = make_pair(H, W, maxd, int(rng.integers(0, 1 << 30)))
+        if flat:
+            L = (L // 64 * 64).astype(np.uint8)
+            R = np.ascontiguousarray(R[:, ::-1])
+        L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+        _, cref = oracle.asw(L, R, winSize=win, maxDisparity=maxd, gammaC=gc, gammaP=gp, return_costs=True)
+        n = 2000
+        ys, xs = rng.integers(0, H, n), rng.integers(0, W, n)
+        ds = np.minimum(rng.integers(0, maxd + 1, n), xs)
+        yxd = np.ascontiguousarray(np.stack([ys, xs, ds], 1).astype(np.int32))
+        costs, l1, l2 = np.empty(n), np.empty((H, W, 3)), np.empty((H, W, 3))
+        _native.check(_native.lib().ssamd_debug_exact_costs(L.ctypes.data, R.ctypes.data, H, W, win, gc, gp, n, yxd.ctypes.data, costs.ctypes.data,
+                                                            l1.ctypes.data, l2.ctypes.data))
+        assert np.array_equal(costs.view(np.uint64), cref[ys, xs, ds].view(np.uint64)), (H, W, win)
+        assert np.array_equal(l1.view(np.uint64), oracle.bgr2lab(L).view(np.uint64)) and np.array_equal(l2.view(np.uint64), oracle.bgr2lab(R).view(np.uint64))
+    x = np.concatenate([rng.random(400000) * 3.0e4, rng.random(200000) * 50.0, (rng.integers(0, 400, 100000) ** 2).astype(np.float64), np.array([0.0, 1.0, 2.0])])
+    out = np.empty_like(x)
+    _native.check(_native.lib().ssamd_debug_libm(2, x.size, x.ctypes.data, out.ctypes.data))
+    assert np.array_equal(out.view(np.uint64), np.sqrt(x).view(np.uint64))
+    _native.check(_native.lib().ssamd_debug_libm(3, x.size, x.ctypes.data, out.ctypes.data))
+    assert np.array_equal(out.view(np.uint64), (x / 0.7 + x / 5.0).view(np.uint64))
+
+
+def test_exact_mode_mini_soak_against_the_oracle(ss):
+    """60 seeded random cases of tools/soak_r05.py's generator (flat / saturated content, windows 3..35, ranges 1..120, plain and
+    consistent, gammaC down to 0.7): every exact-mode map is the fp64 oracle's.  The cases that taught the pass its near-tie
+    rules live here: candidates whose fp32 images differ although the reference's fp64 costs are within its own rounding noise of
+    each other (saturated side: absolute bound ~win^2 ulps of 40), and pairs either side of cost = 20 where the image changes form."""
+    from oracle import oracle
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    rng = np.random.default_rng(5)
+    done = 0
+    for _ in range(60):
+        H, W = int(rng.integers(4, 60)), int(rng.integers(8, 400))
+        win = int(rng.choice([3, 5, 9, 11, 15, 21, 27, 35]))
+        nD, mind = int(rng.integers(1, 121)), int(rng.choice([0, 0, 1, 5]))
+        maxd = mind + nD - 1
+        p = dict(winSize=win, maxDisparity=maxd, minDisparity=mind, consistent=bool(rng.random() < 0.5),
+                 gammaC=float(rng.choice([5.0, 7.0, 0.7, 50.0])), gammaP=float(rng.choice([17.5, 3.0, 100.0])))
+        L, R, _ = make_pair(H, W, max(1, maxd), int(rng.integers(0, 1 << 30)))
+        if rng.random() < 0.4:
+            L = (L // 64 * 64).astype(np.uint8)
+            R = np.ascontiguousarray(R[:, ::-1])
+        L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+        if H * W * nD * win * win > 3e8:
+            continue
+        d = ss.passive.StereoASW(exact=True, **p).compute(L, R)
+        assert _native.counter("exact_overflow") == 0
+        ref = oracle.asw(L, R, **p)
+        assert np.array_equal(d, ref), (H, W, p, int(np.count_nonzero(d != ref)))
+        done += 1
+    assert done >= 40
