@@ -120,12 +120,14 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
 /* ---- ASW with the reference's fp64 argmin on near-ties ("exact" mode, opt-in) -----
  * The reference aggregates in double (_passive.cpp:23, 56-95); ssamd_asw* accumulate in fp32 and may pick the other one of
  * two candidates whose costs agree to ~1e-6 relative (a fraction of a percent of the pixels at worst).  These entry points
- * run the same kernels, then re-evaluate every candidate whose fp32 cost image is within 128 ulps (1.5e-5 relative) of its
- * pixel's winner in fp64 -- the reference's expression and summation order (_passive.cpp:37-50, 57-88), fp64 CIELab
+ * run the same kernels, then re-evaluate every candidate whose fp32 cost image is a near-tie of its pixel's winner (within 1.5e-5
+ * relative; on the saturated side within the reference's own fp64 rounding noise, ~6 win^2 2^-53 40 absolute) in fp64 -- the reference's expression and summation order (_passive.cpp:37-50, 57-88), fp64 CIELab
  * (colorconversion.hpp:67-69), no contraction -- and redo those argmins (first minimum wins, :90-93 / 243-246); both the
  * left- and the right-referenced pass with `consistent`.  Costs H*W*nD*4 bytes of device scratch (1.6 GB at 1080p / 193
- * disparities) and a few per cent of time.  Candidates whose fp64 costs are EQUAL to the last ulps (every tap saturated
- * at the cap 40: costs 40 (1 +- 1e-16)) are where the reference's choice depends on its libm's rounding; there the
+ * disparities) and a few per cent of time.  The weights are the reference's to the bit (glibc's exp and powf restated for the
+ * device, csrc/glibc_math.hip.h; IEEE sqrt and division), so candidates one ulp apart resolve as in the reference too: on the
+ * goldens, the whole bench frame and 11 900 random frames the map IS the reference's -- on hosts whose libm is the FMA build of
+ * glibc >= 2.28; on another libm the reference's own saturated ties differ.  Among exactly equal fp64 costs the
  * smallest index wins, as in ssamd_asw.  Same arguments and buffers as ssamd_asw / ssamd_asw_device. */
 int ssamd_asw_exact(const uint8_t *img1, const uint8_t *img2, int height, int width,
                     int winSize, int maxDisparity, int minDisparity,
