@@ -917,7 +917,8 @@ int asw_exact_pass(Ctx &c, int H, int W, int row0, int rows, int win, int maxD, 
     if ((rc = c.xlabL.reserve(npix * 24)) || (rc = c.xlabR.reserve(npix * 24))) return rc;
     // queue: room for a few candidates of every pixel, bounded (a frame of saturated noise can flag every candidate of every
     // pixel: those entries all evaluate to the same cost and the smallest index wins anyway; an overflow leaves the fp32 map)
-    size_t cap = std::min<size_t>(std::max<size_t>(4 * nout, (size_t)1 << 16), (size_t)1 << 25);
+    // (frames of up to 4M candidates in all get room for every one of them: a flat test image cannot overflow)
+    size_t cap = std::min<size_t>(std::max<size_t>(4 * nout, std::min<size_t>(nout * (size_t)nD + nout, (size_t)1 << 22)), (size_t)1 << 25);
     if (tune().exact_cap) cap = (size_t)tune().exact_cap;
     if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(2 * nout)) ||
         (rc = c.xslots.reserve(nout * 24)) || (rc = c.xctr.reserve(64)))

@@ -209,6 +209,9 @@ class StripContext:
         self.top = min(self.pad, n) if self.h0 < self.r0 else 0        # rows that read halo rows above / below
         self.bot = min(self.pad, n - self.top) if self.h1 > self.r1 else 0
         self.interior = n - self.top - self.bot
+        import os
+        if os.environ.get("SSAMD_STRIP_OVERLAP", "1") == "0":          # escape hatch: the sequential step of rounds 1-4
+            overlap = False
         self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ == "StereoASW" and
                             not getattr(matcher, "alternate", False) and not getattr(matcher, "exact", False) and
                             self.world > 1 and self._ops and self.interior > 0 and self.top + self.bot > 0)
