@@ -77,6 +77,7 @@ struct AswArgs {
                                  //    fp64 tie-break pass compares them with the winning keys (asw_exact_kernels.hip.h)
     int H, W, win, pad, minD, maxD, row0, rows;
     int ystep;                   // output row of workgroup row b: row0 + b * ystep (2: alternate-rows mode)
+    int yb0;                     // first workgroup row of this launch (the half-width tail launch continues the main launch's rows)
     int yskip_at, yskip;         // ... + yskip for b >= yskip_at: TWO row ranges in one launch (the border rows of a row strip whose
                                  //     interior rows ran while the halo was in flight, strips.py); yskip = 0: one range
     float kC;                    // -log2(e)/gammaC
@@ -89,6 +90,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <typename Args>
 __device__ __forceinline__ int asw_out_row(const Args &A, int b)
 {
+    b += A.yb0;
     return A.row0 + b * A.ystep + (b >= A.yskip_at ? A.yskip : 0);
 }
 

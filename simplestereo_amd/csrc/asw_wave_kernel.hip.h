@@ -47,7 +47,7 @@ struct AswWaveArgs {
     const unsigned char *evol;   // TAD volume (required)
     int erow0, erows, evolW;
     int H, W, win, pad, minD, maxD, row0, rows, ystep;
-    int yskip_at, yskip;         // second row range (AswArgs::yskip)
+    int yb0, yskip_at, yskip;    // first workgroup row; second row range (AswArgs::yb0, yskip)
     float kC;
     AswWaveGeom g;
 };

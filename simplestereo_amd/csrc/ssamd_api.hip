@@ -1208,7 +1208,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs; wa.cost_keys = a.cost_keys;
                 wa.evol = a.evol; wa.erow0 = a.erow0; wa.erows = a.erows; wa.evolW = a.evolW;
                 wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
-                wa.ystep = a.ystep; wa.kC = a.kC; wa.yskip_at = a.yskip_at; wa.yskip = a.yskip;
+                wa.ystep = a.ystep; wa.kC = a.kC; wa.yb0 = 0; wa.yskip_at = a.yskip_at; wa.yskip = a.yskip;
                 auto wk = wa.g.RX == 8 ? (d_costs ? asw_aggregate_wave_kernel<true, 8> : asw_aggregate_wave_kernel<false, 8>)
                                        : (d_costs ? asw_aggregate_wave_kernel<true, 4> : asw_aggregate_wave_kernel<false, 4>);
                 // build rounds known at compile time (straight-line build): the common combinations
@@ -1262,7 +1262,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 // (tests/test_gpu_asw.py).  Worth ~4 % at 8.44 rounds, nothing beyond a few dozen; SSAMD_ASW_TAIL=0 / 1 forces.
                 int rows_main = grows;
                 AswGeom tail_g;
-                if (!alternate && skip == 0 && tune().asw_tail != 0 && g.XG >= 4) {
+                if (!alternate && tune().asw_tail != 0 && g.XG >= 4) {
                     // workgroups in flight at a time: the device's CUs x the tile's residency (168 VGPRs -> three waves per SIMD;
                     // the tile's LDS).  One per CU for the 9- to 12-wave tiles of the headline configurations.
                     const int per_simd = (g.threads / 64 + 3) / 4;
@@ -1285,13 +1285,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 if (rows_main < grows) {
                     ++c.tail_splits;
                     AswArgs t = a;
-                    const size_t skip = (size_t)rows_main * W;
                     t.g = tail_g;
-                    t.row0 = row0 + rows_main; t.rows = rows - rows_main;
-                    if (t.disp) t.disp += skip;
-                    if (t.keyL) t.keyL += skip;
-                    if (t.keyR) t.keyR += skip;
-                    if (t.costs) t.costs += skip * (size_t)nD;
+                    t.yb0 = rows_main;              // (workgroup rows continue; outputs are addressed by image row, so the buffers stay put)
                     auto tk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
                     const int tail_lds = a.evol ? tail_g.lds_bytes_evol : tail_g.lds_bytes;
                     if (int grc = grant_dyn_lds(c, (const void *)tk, tail_lds)) return grc;

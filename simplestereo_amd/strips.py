@@ -209,8 +209,16 @@ class StripContext:
         self.top = min(self.pad, n) if self.h0 < self.r0 else 0        # rows that read halo rows above / below
         self.bot = min(self.pad, n - self.top) if self.h1 > self.r1 else 0
         self.interior = n - self.top - self.bot
+        # Two launches instead of one must not cost more rounds of workgroups than they hide exchange time: the interior launch is
+        # cut to whole rounds (8 GPUs, config 3: 135-row strip = 101 interior rows = 6.3 rounds of 256 workgroups at 16 per row ->
+        # 96 rows = 6 rounds; the other 39 rows = 2.4 rounds go to the border launch, whose last part-filled round runs as
+        # half-width tiles), so that interior + border = the rounds of one launch over the strip
         import os
-        if os.environ.get("SSAMD_STRIP_OVERLAP", "1") == "0":          # escape hatch: the sequential step of rounds 1-4
+        mode = os.environ.get("SSAMD_STRIP_OVERLAP", "1")             # "0": the sequential step of rounds 1-4; "force": overlap wherever
+        if mode != "force":                                            # a row is free of the halo, whatever the rounds (tests)
+            self.interior = self._whole_rounds(matcher, self.interior)
+        self.bot = n - self.top - self.interior
+        if mode == "0":
             overlap = False
         self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ == "StereoASW" and
                             not getattr(matcher, "alternate", False) and not getattr(matcher, "exact", False) and
@@ -218,6 +226,26 @@ class StripContext:
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self.strip_out = torch.empty((n, self.W), dtype=torch.int16, device=self.device) if self.overlap else None
         self._timing = None           # list of per-step event tuples while enable_timing() is on (GPU devices only)
+
+    def _whole_rounds(self, matcher, interior):
+        """the largest number of rows <= interior whose workgroups fill whole rounds of the device (0 when that is less than one
+        round or the geometry is unknown: a strip that small is not worth two launches)"""
+        if interior <= 0 or self.device.type != "cuda" or type(matcher).__name__ != "StereoASW":
+            return max(interior, 0)
+        try:
+            import torch
+            from . import _native
+            g = _native.asw_geometry(self.W, interior, int(matcher.winSize), int(matcher.maxDisparity), int(matcher.minDisparity))
+            if _native.asw_kernel_form(self.W, interior, int(matcher.winSize), int(matcher.maxDisparity), int(matcher.minDisparity))["wave_kernel"]:
+                return interior                      # wave kernels: thousands of independent waves, no round structure to respect
+            per_row = g["grid_x"] * g["grid_z"]
+            waves = g["threads"] // 64
+            resident = max(1, min(3 // max(1, (waves + 3) // 4), (160 * 1024) // max(1, g["lds_bytes"])))
+            slots = torch.cuda.get_device_properties(self.device).multi_processor_count * resident
+            rounds = interior * per_row // slots
+            return int(rounds * slots // per_row) if rounds >= 1 else 0
+        except Exception:      # noqa: BLE001 -- a heuristic: never in the way of the step
+            return interior
 
     def enable_timing(self, on=True):
         """Record device events around the phases of every step (halo exchange incl. the strip copies, kernels, gather) on

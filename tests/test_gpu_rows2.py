@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
     (60, 400, dict(winSize=35, maxDisparity=100, minDisparity=2)),         # phase-shifted kernel
     (60, 400, dict(winSize=21, maxDisparity=150, consistent=True)),        # several tiles, keys
     (50, 120, dict(winSize=5, maxDisparity=60)),                           # round-1 kernel (window of one chunk)
+    (52, 1920, dict(winSize=35, maxDisparity=192)),                        # headline tile, 16 workgroups per row: the two-range launch
+                                                                           # has a full round + a part-filled one (half-width tail tiles)
 ])
 def test_two_row_ranges_equal_one_launch(H, W, params):
     import torch

@@ -25,6 +25,8 @@ def _worker(rank, world, port, case, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if case[3].get("_overlap") is not None:
+        os.environ["SSAMD_STRIP_OVERLAP"] = "force"     # small test frames: overlap wherever a row is free of the halo, whatever the rounds
     try:
         import simplestereo_amd as ss
         from simplestereo_amd import strips
@@ -63,6 +65,8 @@ def _worker(rank, world, port, case, q):
     # 32-row strips, 17-row halo: the middle rank has no row that is free of both halos, the outer ranks have 15 (one halo each)
     (3, ("asw", 96, 300, dict(winSize=35, maxDisparity=16, minDisparity=1, _overlap=[True, False, True]))),
     (2, ("asw", 100, 300, dict(winSize=35, maxDisparity=16, _overlap=True))),
+    # default mode (interior launch cut to whole rounds of workgroups, the rest joins the border launch incl. its half-width last round)
+    (2, ("asw", 200, 1920, dict(winSize=35, maxDisparity=192))),
     (3, ("asw", 47, 160, dict(winSize=11, maxDisparity=24, alternate=True))),      # strips of 16 / 16 / 15 rows: odd and even starts
     # BASELINE config 5's partition: eight ranks, 4096 columns, D 0..256, win 35 (the 88 x 260 tiles of the 4K launch); 136
     # rows = eight strips of 17 rows = exactly the halo, so every interior rank receives both halos whole from its neighbours
