@@ -537,6 +537,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     }
 }
 
+#ifndef SSAMD_KERNEL_TU          // (the translation units that only instantiate one aggregation kernel family: asw_pipe_tu.hip, asw_wave6_tu.hip)
 // K2a: decode left keys (non-consistent mode).  disparity = d of the best key, or x
 // when the candidate loop was empty (dBest stays 0, _passive.cpp:54,98).
 // right_keys != 0: the keys are right-referenced (low word = best LEFT column of the right pixel, 0 when its
@@ -597,5 +598,7 @@ __global__ __launch_bounds__(256) void lr_check_fill_kernel(const u64 *__restric
         out[x] = v;
     }
 }
+
+#endif  // SSAMD_KERNEL_TU
 
 }  // namespace ssamd

@@ -38,7 +38,9 @@
 // wR and no swizzle arithmetic.
 #pragma once
 #include "asw_kernels.hip.h"
+#ifndef SSAMD_KERNEL_TU
 #include "lab_kernels.hip.h"
+#endif
 
 #ifndef SSAMD_PIPE_SENTINEL       // 0: the round-2 weight build with masks (A/B builds of tools/build_variants.sh)
 #define SSAMD_PIPE_SENTINEL 1
@@ -46,6 +48,7 @@
 
 namespace ssamd {
 
+#ifndef SSAMD_KERNEL_TU
 // K0e: the truncated absolute differences e[r][u][d] = min(40, |dB|+|dG|+|dR|) of L[r][u] and R[r][u-d]
 // (_passive.cpp:77-79) for every image row the launch touches, as bytes in exactly the layout of the kernel's e
 // tiles: [disparity chunk z][row][column u + pad][Se bytes = one dword per 4 disparities, padded].  e depends on
@@ -175,6 +178,8 @@ __global__ __launch_bounds__(256) void asw_prepass_kernel(const AswPrepassArgs P
     const int b = (int)blockIdx.x - P.lab_blocks, bx = b % P.ex, by = (b / P.ex) % P.ey, bz = b / (P.ex * P.ey);
     asw_tad_tile<true>(P.bgrL, P.bgrR, P.evol, P.W, P.pad, P.minD, P.Dc, P.Se, P.erow0, P.erows, P.evolW, P.rd, P.npix_total, bx, by, bz, smem);
 }
+
+#endif  // SSAMD_KERNEL_TU
 
 // (A 6-column register tile -- 48 accumulators, 128 VGPRs, FOUR waves per SIMD in 1024-thread groups, right weights
 // read as 8-byte pairs -- was built and measured in round 2: bit-identical maps, 43.6 ms against 38.2 ms for this

@@ -24,6 +24,15 @@
 #include "asw_wave_kernel.hip.h"
 #include "asw_wave6_kernel.hip.h"
 #include "asw_alt_kernels.hip.h"
+#ifndef SSAMD_SINGLE_TU          // (-DSSAMD_SINGLE_TU: everything in this translation unit, as until round 4: tools/build_variants.sh)
+namespace ssamd {
+#define SSAMD_PIPE_INSTANCE(C, SL, SR, SE) extern template __global__ void asw_aggregate_pipe_kernel<C, SL, SR, SE>(const AswArgs);
+#define SSAMD_WAVE6_INSTANCE(C, K, CREG) extern template __global__ void asw_aggregate_wave6_kernel<C, K, CREG>(const AswWaveArgs);
+#include "asw_instances.inc"
+#undef SSAMD_PIPE_INSTANCE
+#undef SSAMD_WAVE6_INSTANCE
+}  // namespace ssamd
+#endif
 #include "gsw_kernels.hip.h"
 #include "lab_kernels.hip.h"
 #include "asw_exact_kernels.hip.h"

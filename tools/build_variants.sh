@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p tools/_exp
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fno-slp-vectorize ${flags//,/ } \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fno-slp-vectorize -Wno-int-to-pointer-cast -DSSAMD_SINGLE_TU ${flags//,/ } \
     -o tools/_exp/libssamd_$name.so simplestereo_amd/csrc/ssamd_api.hip &
 done
 wait
