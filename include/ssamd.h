@@ -138,6 +138,11 @@ int ssamd_asw_exact_device(const uint8_t *d_img1, const uint8_t *d_img2, int hei
                            int winSize, int maxDisparity, int minDisparity,
                            double gammaC, double gammaP, int consistent,
                            int16_t *d_disparity, void *stream);
+/* ssamd_asw_multi with the tie-break pass: one row strip per listed GPU, each strip tie-broken on its own device. */
+int ssamd_asw_exact_multi(const uint8_t *img1, const uint8_t *img2, int height, int width,
+                          int winSize, int maxDisparity, int minDisparity,
+                          double gammaC, double gammaP, int consistent,
+                          int16_t *disparity, const int *devices, int n_devices);
 
 /* ---- "alternate pixel" ASW -------------------------------------
  * The faster variant the reference only sketches in a docstring todo (passive.py:43-46: "compute

@@ -78,6 +78,8 @@ def lib():
     L.ssamd_asw_device_rows2.argtypes = [P, P, I, I, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_exact.restype = I
     L.ssamd_asw_exact.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
+    L.ssamd_asw_exact_multi.restype = I
+    L.ssamd_asw_exact_multi.argtypes = [P, P, I, I, I, I, I, D, D, I, P, ctypes.POINTER(I), I]
     L.ssamd_asw_exact_device.restype = I
     L.ssamd_asw_exact_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_alternate.restype = I

@@ -2110,6 +2110,16 @@ int ssamd_asw_multi(const uint8_t *img1, const uint8_t *img2, int height, int wi
                               disparity, nullptr, false), devices, n_devices, asw_host_rows);
 }
 
+int ssamd_asw_exact_multi(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
+                          int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity,
+                          const int *devices, int n_devices)
+{
+    if (!img1 || !img2 || !disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    HostJob j = asw_job(img1, img2, height, width, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent, disparity, nullptr, false);
+    j.exact = true;          // (rows are independent jobs and the tie-break pass is row-local: each strip runs its own)
+    return run_strips(j, devices, n_devices, asw_host_rows);
+}
+
 int ssamd_asw_alternate(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
                         int minDisparity, double gammaC, double gammaP, int consistent, int16_t *disparity, int device)
 {

@@ -176,8 +176,7 @@ class StereoASW():
         its pixel's winner is re-evaluated in fp64 with the reference's own expression and summation order
         (reference ``_passive.cpp:37-50, 57-88``) and those argmins are redone -- the map is then the reference's
         wherever double precision can tell the candidates apart (``ssamd_asw_exact*``, include/ssamd.h).  Costs
-        ``H * W * nDisparities * 4`` bytes of device scratch and a few per cent of time.  Not with ``alternate`` or
-        ``devices=[...]``.
+        ``H * W * nDisparities * 4`` bytes of device scratch and a few per cent of time.  Not with ``alternate`` or ``rectify=``.
     """
 
     def __init__(self, winSize=35, maxDisparity=16, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
@@ -249,10 +248,8 @@ class StereoASW():
         out = np.empty((H, W), np.int16)
         try:
             if devices is not None:
-                if exact:
-                    raise ValueError("exact=True is not available with devices=[...] (use row strips of device tensors: strips.py)")
                 arr, n = _device_list(devices)
-                multi = lib.ssamd_asw_alternate_multi if self._alternate(cons) else lib.ssamd_asw_multi
+                multi = lib.ssamd_asw_alternate_multi if self._alternate(cons) else (lib.ssamd_asw_exact_multi if exact else lib.ssamd_asw_multi)
                 _native.check(multi(a.ctypes.data, b.ctypes.data, H, W, win, maxd, mind, gc, gp, cons, out.ctypes.data, arr, n))
                 return out
             if self._alternate(cons):

@@ -162,8 +162,11 @@ def test_exact_mode_argument_errors(ss):
     L, R, _ = make_pair(24, 64, 8, 1)
     with pytest.raises(ValueError):
         ss.passive.StereoASW(exact=True, alternate=True, maxDisparity=8).compute(L, R)
-    with pytest.raises(ValueError):
-        ss.passive.StereoASW(exact=True, maxDisparity=8).compute(L, R, devices=[0])
+    # devices=[...]: one strip per listed GPU, each tie-broken on its own device (the 1-GPU box lists GPU 0 twice: test hook)
+    from simplestereo_amd import _native
+    with _native.options(SSAMD_MULTI_ALLOW_REPEAT="1"):
+        two = ss.passive.StereoASW(exact=True, maxDisparity=8, winSize=9).compute(L, R, devices=[0, 0])
+    assert np.array_equal(two, ss.passive.StereoASW(exact=True, maxDisparity=8, winSize=9).compute(L, R))
     # empty candidate loops (maxDisparity < minDisparity): nothing to break ties between, same output as the plain call
     a = ss.passive.StereoASW(exact=True, winSize=5, maxDisparity=3, minDisparity=5).compute(L, R)
     assert np.array_equal(a, ss.passive.StereoASW(winSize=5, maxDisparity=3, minDisparity=5).compute(L, R))
