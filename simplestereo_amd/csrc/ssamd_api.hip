@@ -1255,10 +1255,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 auto pk = d_costs ? asw_aggregate_pipe_kernel<true> : asw_aggregate_pipe_kernel<false>;
                 // strides known at compile time for the tiles of the headline configurations (immediate offsets in the
                 // tap steps): 120 x 196 (1080p / D 0..192) and 88 x 260 (4096 x 2160 / D 0..256), 216 x 68 (D 0..64)
-                if (!d_costs && tune().asw_static != 0) {
-                    if (g.SL == 120 && g.SR == 316 && g.Se == 208) pk = asw_aggregate_pipe_kernel<false, 120, 316, 208>;
-                    else if (g.SL == 88 && g.SR == 348 && g.Se == 272) pk = asw_aggregate_pipe_kernel<false, 88, 348, 272>;
-                    else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = asw_aggregate_pipe_kernel<false, 216, 284, 80>;
+                // (with the cost / cost-image dump too: exact=True on the headline tiles ran the run-time-stride form, + 0.9 ms at 1080p / 193)
+                if (tune().asw_static != 0) {
+                    if (g.SL == 120 && g.SR == 316 && g.Se == 208) pk = d_costs ? asw_aggregate_pipe_kernel<true, 120, 316, 208> : asw_aggregate_pipe_kernel<false, 120, 316, 208>;
+                    else if (g.SL == 88 && g.SR == 348 && g.Se == 272) pk = d_costs ? asw_aggregate_pipe_kernel<true, 88, 348, 272> : asw_aggregate_pipe_kernel<false, 88, 348, 272>;
+                    else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = d_costs ? asw_aggregate_pipe_kernel<true, 216, 284, 80> : asw_aggregate_pipe_kernel<false, 216, 284, 80>;
                 }
                 const int pipe_lds = a.evol ? g.lds_bytes_evol : g.lds_bytes;          // (no staged colour bytes when the e tiles come from the volume)
                 if (pipe_lds > 160 * 1024) return fail(SSAMD_ELIMIT, "this tile needs the TAD volume (LDS %d bytes without it)", pipe_lds);
