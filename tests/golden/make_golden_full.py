@@ -11,6 +11,7 @@ WHOLE frame that bench.py times, `simplestereo_amd.synth.make_pair(1080, 1920, 1
     F3p  config 3: ASW win 35, D 0..192, gammaC 5, gammaP 17.5, consistent=False      (~15 min on 8 threads)
     F3c  config 3 with consistent=True  (the reference does two aggregation passes)    (~30 min)
     F4   config 4: GSW class defaults win 11, D 0..192, gamma 10, fMax 120, it 3       (~10 min)
+    F5p  config 5: ASW win 35, D 0..256 on make_pair(2160, 4096, 256, seed=1)         (~1.5 h; only when named)
 
 Output: full_cases.npz (int16 maps, ~1 MB each compressed) + full_cases.json (recipe, parameters, sha256 of the
 map and of the input bytes).  Inputs are regenerated from the recipe (make_pair is deterministic), not stored.
@@ -38,6 +39,9 @@ CASES = {
     "F3p": A(winSize=35, maxDisparity=192, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False),
     "F4": G(winSize=11, maxDisparity=192, minDisparity=0, gamma=10, fMax=120, iterations=3, bins=20),
     "F3c": A(winSize=35, maxDisparity=192, minDisparity=0, gammaC=5, gammaP=17.5, consistent=True),
+    # config 5's frame (bench.py --config c5_4k_d256_w35): make_pair(2160, 4096, 256, seed=1), ~1.5 h on 8 threads
+    "F5p": A(winSize=35, maxDisparity=256, minDisparity=0, gammaC=5, gammaP=17.5, consistent=False,
+             frame=(2160, 4096, 256, 1)),
 }
 
 
@@ -51,16 +55,20 @@ def main():
     ref = _oracle.ref_module()
     if ref is None:
         raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` first")
-    want = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
+    want = [a for a in sys.argv[1:] if a in CASES] or [c for c in CASES if c != "F5p"]
     maps, meta = {}, {}
     if os.path.exists(os.path.join(OUT, "full_cases.npz")):
         old = np.load(os.path.join(OUT, "full_cases.npz"))
         maps = {k: old[k] for k in old.files}
         meta = json.load(open(os.path.join(OUT, "full_cases.json")))
-    H, W, maxD, seed = FRAME
-    L, R, _ = make_pair(H, W, maxD, seed)
+    pairs = {}
     for cid in want:
-        p = CASES[cid]
+        p = dict(CASES[cid])
+        frame = tuple(p.pop("frame", FRAME))
+        H, W, maxD, seed = frame
+        if frame not in pairs:
+            pairs[frame] = make_pair(H, W, maxD, seed)[:2]
+        L, R = pairs[frame]
         t = time.time()
         if p["algo"] == "asw":
             d = ref.computeASW(L, R, p["winSize"], p["maxDisparity"], p["minDisparity"],
@@ -71,8 +79,8 @@ def main():
         dt = time.time() - t
         assert d.dtype == np.int16 and d.shape == (H, W)
         maps[cid] = d
-        meta[cid] = dict(recipe="simplestereo_amd.synth.make_pair(%d,%d,%d,seed=%d), whole frame" % FRAME,
-                         frame=list(FRAME), params=p, shape=[H, W],
+        meta[cid] = dict(recipe="simplestereo_amd.synth.make_pair(%d,%d,%d,seed=%d), whole frame" % frame,
+                         frame=list(frame), params=p, shape=[H, W],
                          sha256=hashlib.sha256(d.tobytes()).hexdigest(), checksum=int(d.astype(np.int64).sum()),
                          input_sha256=hashlib.sha256(L.tobytes() + R.tobytes()).hexdigest(),
                          ref_seconds=round(dt, 1), ref_threads=os.cpu_count())

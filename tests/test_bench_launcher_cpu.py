@@ -51,3 +51,38 @@ def test_single_rank_selftest_needs_no_launcher():
                        text=True, timeout=300, env=_clean_env(), cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _one_json_line(r.stdout)["n_gpus"] == 1
+
+
+def _one_json_line_sized(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8192, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("record", ["r05_d_bench_line.json", "r05_bench_c3_8_ranks_sharing_one_gpu.json"])
+def test_compact_line_of_the_largest_committed_records_stays_under_8_kb(record):
+    """BENCH_r05.json came back `parsed: null`: the round-5 line was ~20 KB.  bench.py now prints a compact line (the contract
+    keys) and writes the full record to bench_details.json; the compaction is a pure function, checked here on the
+    largest full records in profiles/ (the one-GPU line of round 5 and an 8-rank line)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", record)))
+    assert len(json.dumps(full)) > 8192
+    full["_frame_width"] = 1920
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT == 8192, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "details"):
+        assert k in line, k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "launches", "hbm"):
+        assert k in line["roofline"], k
+    assert "workload" in line["config"] and "checksum" in line["config"]
+    if full["n_gpus"] == 1:
+        for k in ("value", "unit", "cores", "kind", "sample", "wall_s", "effective_cores"):
+            assert k in line["cpu_baseline"], k
+        assert line["bad1_vs_cpu_ref"]["percent"] == full["bad1_vs_cpu_ref"]["percent"]
+        assert line["speedup_vs_cpu_baseline"] == full["speedup_vs_cpu_baseline"]
+    else:
+        assert len(line["rccl"]["ranks"]) == full["n_gpus"] and line["rccl"]["world_size"] == full["n_gpus"]
+    assert not any(isinstance(v, str) and len(v) > 260 for v in line.values())

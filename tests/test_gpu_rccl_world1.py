@@ -73,17 +73,32 @@ def test_strip_context_over_nccl_at_world_1():
     assert res["p2p_self"] is True
 
 
-def test_bench_forced_distributed_line_at_world_1():
-    env = dict(os.environ, SSAMD_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()))
+def _details(env, tmp_path):
+    env["SSAMD_BENCH_DETAILS"] = str(tmp_path / "bench_details.json")
+    return env
+
+
+def _read(r, env):
+    """(the ONE compact stdout line the driver parses -- asserted < 8 KB --, the full record bench.py wrote beside it)"""
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 8192, len(lines[0])       # BENCH_r05.json: a ~20 KB line came back "parsed": null
+    line = json.loads(lines[0])
+    assert line["details"] == "bench_details.json"
+    return line, json.load(open(env["SSAMD_BENCH_DETAILS"]))
+
+
+def test_bench_forced_distributed_line_at_world_1(tmp_path):
+    env = _details(dict(os.environ, SSAMD_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port())), tmp_path)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config",
                         "c2_480p_d64_w35", "--no-others", "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600,
                        env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout
+    compact, line = _read(r, env)
+    assert compact["rccl"]["backend"] == "nccl" and compact["rccl"]["ranks"][0]["kernel_ms"] > 0
     rc = line["rccl"]
     assert rc["backend"] == "nccl" and rc["world_size"] == 1 and rc["flat_all_gather_into_tensor"] is True
     assert rc["p2p_loopback_probe"] is True
@@ -95,24 +110,25 @@ def test_bench_forced_distributed_line_at_world_1():
                         env=env, cwd=ROOT)
     assert r2.returncode == 0, r2.stderr[-3000:]
     plain = json.loads([l for l in r2.stdout.splitlines() if l.strip()][-1])
+    assert len(r2.stdout.strip()) < 8192
     assert plain["config"]["checksum"] == line["config"]["checksum"]
     assert "rccl" not in plain
 
 
-def test_bench_line_of_a_two_rank_run_explains_itself():
+def test_bench_line_of_a_two_rank_run_explains_itself(tmp_path):
     """the N > 1 branches of bench.py -- slowest rank's roofline, per-rank kernel ms, the gathered map against ONE launch over
     the whole frame, the accuracy figure computed THROUGH the strips -- executed with two ranks sharing GPU 0 over gloo
     (SSAMD_BENCH_SHARE_GPU: RCCL refuses two ranks on one device); launched the way the driver launches a scaling run"""
-    env = dict(os.environ, SSAMD_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    env = _details(dict(os.environ, SSAMD_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1"), tmp_path)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SSAMD_BENCH_FORCE_DIST", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--config", "c2_480p_d64_w35"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    line = json.loads(lines[0])
+    compact, line = _read(r, env)
+    assert compact["n_gpus"] == 2 and compact["rccl"]["world_size"] == 2 and len(compact["rccl"]["ranks"]) == 2
+    assert compact["config"]["checksum_equals_single_gpu"] is True and compact["bad1_vs_cpu_ref"]["percent"] <= 0.5
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     rc = line["rccl"]
     assert rc["world_size"] == 2 and len(rc["ranks"]) == 2 and "shared_gpu_test_mode" in rc
@@ -129,19 +145,31 @@ def test_bench_line_of_a_two_rank_run_explains_itself():
     assert b["cases"]["P2a"]["exact_percent"] >= 99.0
 
 
-def test_bench_line_carries_the_contract_keys():
+def test_bench_line_carries_the_contract_keys(tmp_path):
     """the line the driver parses: metric / value / unit / steps, `roofline` {bound, achieved, peak, unit, frac, traffic},
     `cpu_baseline` {value, unit, cores, kind, sample}, the accuracy figure on the reference's strips -- on a small
     configuration with a tiny CPU sample so that the test stays short"""
-    env = dict(os.environ)
+    env = _details(dict(os.environ), tmp_path)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SSAMD_BENCH_FORCE_DIST"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--config", "c2_480p_d64_w35",
                         "--no-others", "--no-e2e", "--cpu-crop-cols", "96"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout
+    compact, line = _read(r, env)
+    # the compact line alone carries the contract (what the driver sees) ...
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "bad1_vs_cpu_ref"):
+        assert k in compact, k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "launches", "hbm"):
+        assert k in compact["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample", "wall_s", "effective_cores"):
+        assert k in compact["cpu_baseline"], k
+    assert compact["value"] == line["value"] and compact["roofline"]["frac"] == line["roofline"]["frac"]
+    assert compact["cpu_baseline"]["value"] == line["cpu_baseline"]["value"] and len(compact["cpu_baseline"]["sample"]) < 200
+    assert compact["bad1_vs_cpu_ref"]["percent"] == line["bad1_vs_cpu_ref"]["percent"]
+    assert compact["bad1_vs_cpu_ref"]["exact_mode"]["differing_pixels"] == 0
+    # ... and the full record beside it keeps everything else
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline", "bad1_vs_cpu_ref"):
         assert k in line, k
