@@ -384,13 +384,16 @@ def others(dev, seed):
             ("c2_480p_d64_w35", "c2_480p_d64_w35", False),
             ("default_1080p_d16_w35", "default_1080p_d16_w35", False), ("small_1080p_d7_w35", "small_1080p_d7_w35", False),
             ("c5_4k_d256_w35_1gpu", "c5_4k_d256_w35", False)]
-    jobs += [("c3_1080p_d192_w35_exact", "c3_1080p_d192_w35", "exact"), ("c3_1080p_d192_w35_consistent_exact", "c3_1080p_d192_w35", "exact+consistent")]
+    # the same configurations WITHOUT the fp64 tie-break pass (StereoASW(exact=False): the fp32 argmin of rounds 1-5's default path)
+    jobs += [("c3_1080p_d192_w35_fp32", "c3_1080p_d192_w35", "fp32"), ("c3_1080p_d192_w35_consistent_fp32", "c3_1080p_d192_w35", "fp32+consistent"),
+             ("c2_480p_d64_w35_fp32", "c2_480p_d64_w35", "fp32"), ("default_1080p_d16_w35_fp32", "default_1080p_d16_w35", "fp32"),
+             ("c1_tsukuba_d16_w15_fp32", "c1_tsukuba_d16_w15", "fp32"), ("c5_4k_d256_w35_1gpu_fp32", "c5_4k_d256_w35", "fp32")]
     for name, cfgname, consistent in jobs:
         try:
             H, W, maxD, minD, win = CONFIGS[cfgname]
             tL, tR = pair(H, W, maxD)
-            exact = isinstance(consistent, str)           # opt-in fp64 tie-break pass: the reference's map bit for bit
-            consistent = consistent is True or consistent == "exact+consistent"
+            exact = not isinstance(consistent, str)       # the default: fp64 tie-break pass on -- the reference's map bit for bit
+            consistent = consistent is True or consistent == "fp32+consistent"
             m = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
                                      consistent=consistent, exact=exact)
             wall, k_ms, checksum = time_matcher(m, tL, tR, _native.K_ASW_AGG)
@@ -405,14 +408,12 @@ def others(dev, seed):
                          # share of the work for small disparity ranges, ~1.5 % at D 0..192
                          "weight_lane_ops": wops,
                          "valu_frac_with_weights": (VALU_OPS_PER_TAP * taps + wops) / (k_ms * 1e-3) / VALU_PEAK_LANEOPS if k_ms else None,
-                         "issue": replayed_issue(cfgname, k_ms) if not (consistent or exact) else None,
-                         "kernel_form": _native.asw_kernel_form(W, H, win, maxD, minD)}
+                         "issue": replayed_issue(cfgname, k_ms) if not consistent else None,
+                         "kernel_form": _native.asw_kernel_form(W, H, win, maxD, minD), "exact": exact}
             if exact:
-                res[name].update({"exact": True, "candidates_reevaluated": _native.counter("exact_entries"),
+                res[name].update({"candidates_reevaluated": _native.counter("exact_entries"),
                                   "pixels_flagged": [_native.counter("exact_flagged_left"), _native.counter("exact_flagged_right")],
-                                  "queue_overflow": _native.counter("exact_overflow"),
-                                  "note": "StereoASW(exact=True): kernel_ms is the aggregation kernel WITH its cost-image dump; ms_per_step "
-                                          "includes the fp64 pass; the map against the reference: bad1_vs_cpu_ref.exact_mode"})
+                                  "queue_overflow": _native.counter("exact_overflow")})
         except Exception as e:      # noqa: BLE001
             res[name] = {"error": repr(e)[:200]}
     for name, (H, W, maxD, minD, win) in GSW_CONFIGS.items():
@@ -506,26 +507,33 @@ def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
                       "consistent": bool(p.get("consistent", True if gsw else False)), "maxDisparity": p["maxDisparity"],
                       "minDisparity": p["minDisparity"], "recipe": what}
     through = "one launch per case" if world == 1 else "StripContext over %d ranks (row strips, RCCL halo exchange, all_gather)" % world
-    exact_mode = None
+    exact_mode = fp32_mode = None
     if head in cases and world == 1:
-        # the same frame through the opt-in fp64 tie-break pass (StereoASW(exact=True)): the reference's map itself
-        try:
-            m = fmeta[head]
-            p = {k: v for k, v in m["params"].items() if k != "algo"}
-            a, b = frames[tuple(m["frame"])]
-            d = ss.passive.StereoASW(exact=True, **p).compute(a, b)
-            diff = np.abs(d.astype(np.int32) - fmaps[head].astype(np.int32))
-            from simplestereo_amd import _native
-            exact_mode = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
-                          "differing_pixels": int(np.count_nonzero(diff)), "pixels": int(diff.size),
-                          "candidates_reevaluated": _native.counter("exact_entries"), "queue_overflow": _native.counter("exact_overflow"),
-                          "what": "StereoASW(exact=True) on the whole bench frame against the same reference map (%s)" % head}
-        except Exception as e:      # noqa: BLE001
-            exact_mode = {"error": repr(e)[:200]}
+        # the same frame with the fp64 tie-break pass explicitly on (= the default since round 6, DESIGN 4.7: the reference's map
+        # itself) and explicitly off (StereoASW(exact=False): the fp32 argmin, the default of rounds 1-5)
+        from simplestereo_amd import _native
+        for flag in (True, False):
+            try:
+                m = fmeta[head]
+                p = {k: v for k, v in m["params"].items() if k != "algo"}
+                a, b = frames[tuple(m["frame"])]
+                d = ss.passive.StereoASW(exact=flag, **p).compute(a, b)
+                diff = np.abs(d.astype(np.int32) - fmaps[head].astype(np.int32))
+                r = {"percent": 100.0 * float(np.mean(diff > 1)), "exact_percent": 100.0 * float(np.mean(diff == 0)),
+                     "differing_pixels": int(np.count_nonzero(diff)), "pixels": int(diff.size),
+                     "what": "StereoASW(exact=%s) on the whole bench frame against the same reference map (%s)" % (flag, head)}
+                if flag:
+                    r.update({"candidates_reevaluated": _native.counter("exact_entries"), "queue_overflow": _native.counter("exact_overflow")})
+            except Exception as e:      # noqa: BLE001
+                r = {"error": repr(e)[:200]}
+            if flag:
+                exact_mode = r
+            else:
+                fp32_mode = r
     if head in cases:
         h = cases[head]
         return {"percent": h["percent"], "exact_percent": h["exact_percent"], "pixels": h["pixels"], "bad1_pixels": h["bad1_pixels"],
-                "differing_pixels": h["differing_pixels"], "headline_case": head, "tie_exclusion": "none", "exact_mode": exact_mode,
+                "differing_pixels": h["differing_pixels"], "headline_case": head, "tie_exclusion": "none", "exact_mode": exact_mode, "fp32_mode": fp32_mode,
                 "cases": cases, "through": through,
                 "source": "tests/golden/full_cases.npz %s: the WHOLE frame of this run (make_pair(1080,1920,192,seed=1), D 0..192, win 35, "
                           "consistent=%s) through the unmodified reference (_passive.cpp via oracle/_ref, "
@@ -672,13 +680,15 @@ def compact_line(full):
         b = _pick(b1, ("percent", "exact_percent", "pixels", "bad1_pixels", "differing_pixels", "headline_case", "crop_percent"))
         if isinstance(b1.get("exact_mode"), dict):
             b["exact_mode"] = _pick(b1["exact_mode"], ("percent", "differing_pixels", "candidates_reevaluated", "queue_overflow", "error"))
-        if isinstance(b1.get("crop_exact_mode"), dict):
-            b["crop_exact_mode"] = _pick(b1["crop_exact_mode"], ("percent", "exact_percent"))
+        if isinstance(b1.get("fp32_mode"), dict):
+            b["fp32_mode"] = _pick(b1["fp32_mode"], ("percent", "differing_pixels", "error"))
+        if isinstance(b1.get("crop_fp32_mode"), dict):
+            b["crop_fp32_mode"] = _pick(b1["crop_fp32_mode"], ("percent", "exact_percent"))
         if b1.get("percent") is None and "source" in b1:
             b["source"] = str(b1["source"])[:200]
         line["bad1_vs_cpu_ref"] = b
-    for k in ("speedup_vs_cpu_baseline", "speedup_vs_cpu_baseline_cores", "speedup_per_effective_core", "exact_ms_per_step",
-              "exact_overhead_percent", "default_mode"):
+    for k in ("speedup_vs_cpu_baseline", "speedup_vs_cpu_baseline_cores", "speedup_per_effective_core", "default_mode", "fp32_ms_per_step",
+              "exact_overhead_percent", "exact_pass_ms"):
         if k in full:
             line[k] = full[k]
     rc = full.get("rccl")
@@ -955,6 +965,28 @@ def main():
                 line["config"]["checksum_equals_single_gpu"] = repr(e)[:160]
             if bad1_dist is not None:
                 line["bad1_vs_cpu_ref"] = bad1_dist
+        line["default_mode"] = ("exact: StereoASW(exact=\"auto\") -- near-ties of every winner selected in the aggregation kernel and re-decided in "
+                                "fp64 in the reference's arithmetic (DESIGN 4.7); the timed region runs this")
+        if launches[_native.K_ASW_EXACT]:
+            line["exact_pass_ms"] = ms[_native.K_ASW_EXACT] / max(1, args.steps)
+        if world == 1 and not use_dist:
+            # the same frame WITHOUT the tie-break pass (the default of rounds 1-5), alternating with the default so that both see the
+            # same clocks: what the reference's own map costs
+            try:
+                m32 = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
+                                           consistent=args.consistent, exact=False)
+                m32.compute(ownL, ownR)
+                torch.cuda.synchronize()
+                t32, t64 = [], []
+                for _ in range(max(3, min(10, args.steps))):
+                    ta = time.perf_counter(); m32.compute(ownL, ownR); torch.cuda.synchronize(); t32.append(time.perf_counter() - ta)
+                    ta = time.perf_counter(); matcher.compute(ownL, ownR); torch.cuda.synchronize(); t64.append(time.perf_counter() - ta)
+                line["fp32_ms_per_step"] = float(np.median(t32)) * 1e3
+                line["exact_ms_per_step_same_loop"] = float(np.median(t64)) * 1e3
+                line["exact_overhead_percent"] = 100.0 * (float(np.median(t64)) / float(np.median(t32)) - 1.0)
+            except Exception as e:      # noqa: BLE001
+                line["fp32_ms_per_step"] = None
+                line["exact_overhead_error"] = repr(e)[:160]
         if world == 1 and not args.consistent and args.with_alternate:
             # informational, outside the timed region: the opt-in alternate-rows mode on the same frame
             alt = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
@@ -1003,6 +1035,7 @@ def main():
                 r0s, rws, c0s, cls = cb["strip_row0"], cb["strip_rows"], cb["strip_col0"], cb["strip_cols"]
                 gpu_map = matcher.compute(np.ascontiguousarray(L[r0s:r0s + rws, c0s:c0s + cls]),
                                           np.ascontiguousarray(R[r0s:r0s + rws, c0s:c0s + cls]))
+                cand, ovf = _native.counter("exact_entries"), _native.counter("exact_overflow")
                 diff = np.abs(gpu_map.astype(np.int32) - ref_map.astype(np.int32))
                 crop = {"crop_percent": 100.0 * float(np.mean(diff > 1)), "crop_exact_percent": 100.0 * float(np.mean(diff == 0)),
                         "crop_pixels": int(diff.size),
@@ -1030,16 +1063,16 @@ def main():
                     line["bad1_vs_cpu_ref"]["crop_numerical_ties_among_bad1_percent"] = 100.0 * float(np.mean((diff > 1) & tie))
                     tie6 = np.abs(cr_ - cg) <= 1e-6 * np.maximum(1.0, np.abs(cg))
                     line["bad1_vs_cpu_ref"]["crop_percent_excluding_ties_at_1e-6"] = 100.0 * float(np.mean((diff > 1) & ~tie6))
-                    # the same crop through the fp64 tie-break pass (StereoASW(exact=True)): what is left are candidates whose
-                    # fp64 costs are EQUAL to the last ulps (every tap saturated), where the reference's pick is its libm's rounding
+                    line["bad1_vs_cpu_ref"]["crop_exact_mode"] = {"percent": crop["crop_percent"], "exact_percent": crop["crop_exact_percent"],
+                                                                  "candidates_reevaluated": cand, "queue_overflow": ovf}
+                    # the same crop WITHOUT the fp64 tie-break pass (exact=False, the default of rounds 1-5): saturated candidates whose
+                    # fp64 costs agree to the last ulps are where the fp32 argmin and the reference part
                     xm = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
-                                              consistent=bool(args.consistent), exact=True).compute(cl, cr)
+                                              consistent=bool(args.consistent), exact=False).compute(cl, cr)
                     xdiff = np.abs(xm.astype(np.int32) - ref_map.astype(np.int32))
-                    line["bad1_vs_cpu_ref"]["crop_exact_mode"] = {"percent": 100.0 * float(np.mean(xdiff > 1)),
-                                                                  "exact_percent": 100.0 * float(np.mean(xdiff == 0)),
-                                                                  "pixels_changed_by_the_tie_break": int(np.count_nonzero(xm != gpu_map)),
-                                                                  "candidates_reevaluated": _native.counter("exact_entries"),
-                                                                  "queue_overflow": _native.counter("exact_overflow")}
+                    line["bad1_vs_cpu_ref"]["crop_fp32_mode"] = {"percent": 100.0 * float(np.mean(xdiff > 1)),
+                                                                 "exact_percent": 100.0 * float(np.mean(xdiff == 0)),
+                                                                 "pixels_changed_by_the_tie_break": int(np.count_nonzero(xm != gpu_map))}
                 except Exception as e:      # noqa: BLE001
                     line["bad1_vs_cpu_ref"]["crop_percent_excluding_numerical_ties"] = repr(e)[:120]
             except Exception as e:      # noqa: BLE001

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSAMD_ABI_VERSION 4      /* 4: ssamd_asw_exact* (round 5); 3: GSW autotuning; 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
+#define SSAMD_ABI_VERSION 5      /* 5: ssamd_asw_exact_device_rows2 / _rectified_device (round 6: near-ties selected inside the aggregation kernels); 4: ssamd_asw_exact* (round 5); 3: GSW autotuning; 2: ssamd_set_option (round 3) + the multi-device and verification entry points added in round 2 */
 
 #define SSAMD_OK 0
 #define SSAMD_EINVAL (-1)     /* bad argument (message tells which)            */
@@ -117,18 +117,19 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream);
 
-/* ---- ASW with the reference's fp64 argmin on near-ties ("exact" mode, opt-in) -----
+/* ---- ASW with the reference's fp64 argmin on near-ties ("exact" mode; what StereoASW runs by default since round 6) -----
  * The reference aggregates in double (_passive.cpp:23, 56-95); ssamd_asw* accumulate in fp32 and may pick the other one of
  * two candidates whose costs agree to ~1e-6 relative (a fraction of a percent of the pixels at worst).  These entry points
- * run the same kernels, then re-evaluate every candidate whose fp32 cost image is a near-tie of its pixel's winner (within 1.5e-5
- * relative; on the saturated side within the reference's own fp64 rounding noise, ~6 win^2 2^-53 40 absolute) in fp64 -- the reference's expression and summation order (_passive.cpp:37-50, 57-88), fp64 CIELab
- * (colorconversion.hpp:67-69), no contraction -- and redo those argmins (first minimum wins, :90-93 / 243-246); both the
- * left- and the right-referenced pass with `consistent`.  Costs H*W*nD*4 bytes of device scratch (1.6 GB at 1080p / 193
- * disparities) and a few per cent of time.  The weights are the reference's to the bit (glibc's exp and powf restated for the
- * device, csrc/glibc_math.hip.h; IEEE sqrt and division), so candidates one ulp apart resolve as in the reference too: on the
- * goldens, the whole bench frame and 11 900 random frames the map IS the reference's -- on hosts whose libm is the FMA build of
- * glibc >= 2.28; on another libm the reference's own saturated ties differ.  Among exactly equal fp64 costs the
- * smallest index wins, as in ssamd_asw.  Same arguments and buffers as ssamd_asw / ssamd_asw_device. */
+ * run the same kernels, whose epilogue queues every candidate that is a near-tie of its pixel's winner (within 1.5e-5 relative at
+ * gammaC = 5 / winSize <= 35, wider for smaller gammaC and larger windows; on the saturated side within the reference's own fp64
+ * rounding noise, ~6 win^2 2^-53 40 absolute), re-evaluate the queue in fp64 -- the reference's expression and summation order
+ * (_passive.cpp:37-50, 57-88), fp64 CIELab (colorconversion.hpp:67-69), no contraction -- and redo those argmins (first minimum
+ * wins, :90-93 / 243-246); both the left- and the right-referenced pass with `consistent`.  Scratch: O(H*W) (fp64 Lab images
+ * 48 B / pixel, queue and slots 40 B / pixel; round 5 needed H*W*nD*4 bytes).  The weights are the reference's to the bit (glibc's
+ * exp and powf restated for the device, csrc/glibc_math.hip.h; IEEE sqrt and division), so candidates one ulp apart resolve as in
+ * the reference too: on the goldens, the whole bench frames and 38 642 random frames the map IS the reference's.  Among exactly
+ * equal fp64 costs the smallest index wins, as in ssamd_asw.  A queue overflow (ssamd_counter "exact_overflow") keeps the fp32
+ * map.  Same arguments and buffers as ssamd_asw / ssamd_asw_device / ssamd_asw_device_rows2 / ssamd_asw_rectified_device. */
 int ssamd_asw_exact(const uint8_t *img1, const uint8_t *img2, int height, int width,
                     int winSize, int maxDisparity, int minDisparity,
                     double gammaC, double gammaP, int consistent,
@@ -138,6 +139,11 @@ int ssamd_asw_exact_device(const uint8_t *d_img1, const uint8_t *d_img2, int hei
                            int winSize, int maxDisparity, int minDisparity,
                            double gammaC, double gammaP, int consistent,
                            int16_t *d_disparity, void *stream);
+int ssamd_asw_exact_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                                 int out_row0, int out_rows, int skip_row0, int skip_rows,
+                                 int winSize, int maxDisparity, int minDisparity,
+                                 double gammaC, double gammaP, int consistent,
+                                 int16_t *d_disparity, void *stream);
 /* ssamd_asw_multi with the tie-break pass: one row strip per listed GPU, each strip tie-broken on its own device. */
 int ssamd_asw_exact_multi(const uint8_t *img1, const uint8_t *img2, int height, int width,
                           int winSize, int maxDisparity, int minDisparity,
@@ -196,6 +202,12 @@ int ssamd_asw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int
                                const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
                                int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
                                double gammaC, double gammaP, int consistent, int16_t *d_disparity, void *stream);
+
+/* ... with the fp64 tie-break pass (ssamd_asw_exact*): the records carry the remapped bytes, which is all the pass reads */
+int ssamd_asw_exact_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
+                                     const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
+                                     int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
+                                     double gammaC, double gammaP, int consistent, int16_t *d_disparity, void *stream);
 
 /* The same for StereoGSW (_rigs.py:543-567 feeding passive.py:153): raw frames through the rig's maps straight into the
  * matcher's packed pixels, one launch for both images. */

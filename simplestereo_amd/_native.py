@@ -17,7 +17,7 @@ if os.environ.get("SSAMD_LIB"):
         raise ImportError("SSAMD_LIB is an experiment hook: set SSAMD_EXPERIMENT=1 as well to load %s instead of the product "
                           "library" % os.environ["SSAMD_LIB"])
     LIB_PATH = os.environ["SSAMD_LIB"]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 K_LAB, K_ASW_AGG, K_ASW_FIN, K_GSW_AGG, K_GSW_FIN, K_REMAP, K_REPROJECT, K_ASW_ALT, K_ASW_EXACT, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
@@ -82,6 +82,10 @@ def lib():
     L.ssamd_asw_exact_multi.argtypes = [P, P, I, I, I, I, I, D, D, I, P, ctypes.POINTER(I), I]
     L.ssamd_asw_exact_device.restype = I
     L.ssamd_asw_exact_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_asw_exact_device_rows2.restype = I
+    L.ssamd_asw_exact_device_rows2.argtypes = [P, P, I, I, I, I, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_asw_exact_rectified_device.restype = I
+    L.ssamd_asw_exact_rectified_device.argtypes = [P, P, I, I, P, P, P, P, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_alternate.restype = I
     L.ssamd_asw_alternate.argtypes = [P, P, I, I, I, I, I, D, D, I, P, I]
     L.ssamd_asw_alternate_device.restype = I

@@ -1,32 +1,32 @@
-// K1x: fp64 tie-break pass of the ASW matchers (opt-in `exact` mode; gfx950).
+// K1x: fp64 tie-break pass of the ASW matchers (`exact` mode; gfx950).
 //
 // The reference aggregates in double (_passive.cpp:23, 56-95); the aggregation kernels accumulate (N, S') in fp32 and
 // resolve costs to ~1e-6 relative.  Where two candidates of a pixel are closer than that, the fp32 argmin may pick the
-// other one (0.0004 % of the pixels of the bench frame, 0.09 % on the class-default lawn photograph).  This pass makes the
+// other one (0.006 % of the pixels of the bench frame, 0.09 % on the class-default lawn photograph).  This pass makes the
 // argmin the reference's wherever fp64 can tell the candidates apart:
 //
-//   1. the aggregation kernel also dumps the 32-bit cost image of every candidate it evaluates (the `costs` dump the
-//      verification entry points already have, holding asw_cost_key() images instead of floats: H*W*nD*4 bytes of HBM,
-//      1.6 GB at 1080p / 193 -- 0.4 ms to write at HBM speed next to a 36 ms aggregation; 288 GB make that affordable);
-//   2. asw_exact_flag_kernel reads the volume once, coalesced: a candidate whose key image is within `tol` ulps of its
-//      pixel's winning key (left-referenced: keyL[y][x]; right-referenced: keyR[y][x - d]) and is not the winner itself
-//      is appended to a queue, and the pixel is flagged; asw_exact_winners_kernel appends the winners of flagged pixels;
+//   1. (round 6) the aggregation kernels themselves, in their epilogue, queue every candidate that is a NEAR-TIE of its pixel's
+//      winner and flag the pixel (asw_exact_select / asw_exact_merge, asw_kernels.hip.h): the keys are still in registers and
+//      the tile-local winners in LDS there.  Round 5 dumped the cost image of EVERY candidate to HBM (H*W*nD*4 bytes: 1.6 GB at
+//      1080p / 193, 9.1 GB at 4K) and re-read it in a flag kernel to find 0.006 % of it;
+//   2. asw_exact_winners_kernel appends the winners of flagged pixels and initialises their result slots;
 //   3. asw_exact_eval_kernel: one WAVE per queue entry re-evaluates that candidate's cost in fp64 with the reference's
 //      own expression and summation order (window-row-major taps, `cost += w1*w2*TAD; tot += w1*w2`, no contraction:
 //      _passive.cpp:57-88; the tap products side by side on the lanes, the two running sums by one lane in the reference's
-//      order) from fp64 Lab values (colorconversion.hpp:67-69) and a proximity table built by the host's libm
-//      (_passive.cpp:360-364), and atomicMin's the cost's bit pattern into the pixel's slot;
+//      order) from fp64 Lab values (colorconversion.hpp:67-69) and the fp64 proximity table (_passive.cpp:360-364), and
+//      atomicMin's the cost's bit pattern into the pixel's slot;
 //   4. asw_exact_resolve_kernel: among the entries whose cost EQUALS the slot's minimum the smallest index wins (the
 //      reference's strict `<` scan keeps the first minimum, _passive.cpp:90-93 / 243-246);
-//   5. asw_exact_patch_kernel writes the winning index into the low word of the flagged pixels' WTA keys; decode,
-//      left-right check and occlusion filling then run unchanged.
+//   5. asw_exact_patch_kernel writes the winning index into the flagged pixels' WTA keys -- or straight into the disparity map
+//      when the aggregation wrote that itself (one disparity chunk, no right pass); decode, left-right check and occlusion
+//      filling then run unchanged.
 //
-// Bit-identity (round 5): the weights are the reference's to the bit -- fp64 Lab values through glibc's powf, exp through
-// glibc's exp (both restated in glibc_math.hip.h and proven equal to the running libm by oracle/libm_check.c), IEEE sqrt and
-// division, the host libm's proximity table, no contraction -- so even candidates that differ in the last ulp of 40 (1 - k ulp)
-// (every tap saturated: profiles/r05_exact_mode_audit.txt) resolve as in the reference, on hosts whose libm is the FMA build of
-// glibc >= 2.28 (every x86-64 CPU since 2013).  What can still differ: a candidate the fp32 kernels put more than `tol` ulps
-// from their winner although it wins in fp64 (none seen), and a queue overflow (counted).
+// Bit-identity: the weights are the reference's to the bit -- fp64 Lab values through glibc's powf, exp through glibc's exp
+// (both restated in glibc_math.hip.h and proven equal to the running libm by oracle/libm_check.c), IEEE sqrt and division, no
+// contraction -- so even candidates that differ in the last ulp of 40 (1 - k ulp) (every tap saturated:
+// profiles/r05_exact_mode_audit.txt) resolve as in the reference.  What can still differ: a candidate the fp32 kernels put
+// more than the near-tie band from their winner although it wins in fp64 (none seen; the band grows with the window,
+// ssamd_api.hip), and a queue overflow (counted, reported, the fp32 map is kept).
 #pragma once
 #include "asw_kernels.hip.h"
 #include "lab_kernels.hip.h"
@@ -37,19 +37,14 @@ namespace ssamd {
 struct AswExactArgs {
     const PixRec *recL, *recR;       // [H][W] records (bgrx = the raw bytes)
     const double *labL, *labR;       // [H][W][3] fp64 CIELab (rows the call touches)
-    const double *prox;              // [win*win] proximity weights, host libm
-    const uint32_t *kvol;            // [rows][W][nD] cost images of every candidate (undefined where x - d < 0)
-    u64 *keyL, *keyR;                // [rows][W] WTA keys of the aggregation (keyR may be null)
-    unsigned char *flagL, *flagR;    // [rows][W] pixel has near-ties
-    u64 *entries;                    // queue: pix (32) | d (16) << 32 | sides (2) << 48
-    unsigned int *counter;           // [0] entries appended (may exceed cap), [1] flagged left pixels, [2] flagged right pixels
-    unsigned int cap;
+    const double *prox;              // [win*win] fp64 proximity weights
+    u64 *keyL, *keyR;                // [rows][W] WTA keys of the aggregation (keyL null: `disp` holds the left winners; keyR may be null)
+    int16_t *disp;                   // [rows][W] the map the aggregation kernel wrote itself (keyL == nullptr)
+    AswExactQueue q;                 // queue, counters, pixel flags (filled by the aggregation kernels)
     double *ecost;                   // [cap] fp64 cost of each entry
-    u64 *costL, *costR;              // [rows][W] minimum fp64 cost bits over the pixel's entries
+    u64 *costL, *costR;              // [rows][W] minimum fp64 cost bits over the pixel's entries (initialised for flagged pixels)
     uint32_t *idxL, *idxR;           // [rows][W] smallest index among the entries at that minimum
     int H, W, win, pad, minD, maxD, row0, rows;
-    uint32_t tol;                    // key ulps
-    float sat_abs;                   // absolute cost difference below which two saturated candidates are a near-tie of the reference's fp64
     double gammaC;
 };
 
@@ -63,28 +58,6 @@ __device__ __forceinline__ double exact_sqrt(double x)
     if (!(y0 > 0.0) || !(y0 < 1.0e300)) return y0;                   // 0, nan, inf
     const double e = fma(-y0, y0, x);
     return y0 + e / (2.0 * y0);
-}
-
-static constexpr unsigned EXACT_SIDE_L = 1u, EXACT_SIDE_R = 2u;
-// cost images (asw_cost_key) at or above this hold 40 - cost (cost > 20)
-static constexpr uint32_t EXACT_KEY_HIGH = 0xC0000000u - 0x41A00000u;      // 0x41A00000 = bits of 20.0f
-
-// is candidate image `key` a near-tie of the winning image `kb` (kb <= key)?
-__device__ __forceinline__ bool exact_near(uint32_t key, uint32_t kb, uint32_t tol, float sat_abs)
-{
-    if (key - kb <= tol) return true;
-    if (key >= EXACT_KEY_HIGH) {
-        const float inv = __uint_as_float(0xC0000000u - key);                                   // 40 - cost of the candidate
-        if (kb >= EXACT_KEY_HIGH) return __uint_as_float(0xC0000000u - kb) - inv <= sat_abs;
-        // the two images lie either side of cost = 20 (the winner's holds its cost, the candidate's 40 - cost): ulps do not compare
-        return (40.0f - inv) - __uint_as_float(kb) <= 20.0f * 1.1920929e-7f * (float)tol;
-    }
-    return false;
-}
-
-__device__ __forceinline__ u64 exact_entry(uint32_t pix, int d, unsigned sides)
-{
-    return (u64)pix | ((u64)(uint32_t)d << 32) | ((u64)sides << 48);
 }
 
 // fp64 Lab of the rows [r0, r0 + npix / W) from the records' bytes, both images in one launch
@@ -105,53 +78,36 @@ __global__ __launch_bounds__(256) void bgr2lab_f64_pair_kernel(const PixRec *__r
     }
 }
 
-// 2. one thread per (x, d) element of an output row's slice of the key volume
-__global__ __launch_bounds__(256) void asw_exact_flag_kernel(const AswExactArgs A)
-{
-    const int nD = A.maxD - A.minD + 1;
-    const long long per_row = (long long)A.W * nD;
-    const int yr = blockIdx.y;
-    const uint32_t *const krow = A.kvol + (size_t)yr * per_row;
-    const u64 *const kl = A.keyL + (size_t)yr * A.W, *const kr = A.keyR ? A.keyR + (size_t)yr * A.W : nullptr;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per_row; e += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(e / nD), d = A.minD + (int)(e - (long long)x * nD);
-        if (x - d < 0) continue;                                   // not a candidate the reference evaluates (_passive.cpp:56)
-        const uint32_t key = krow[e];
-        unsigned sides = 0;
-        // near-tie: within `tol` ulps of the winner's cost image -- or, on the saturated side of the image (cost > 20: the image
-        // holds 40 - cost), within `sat_abs` of it in ABSOLUTE terms: the (N, S') pair resolves 40 - 1e-30 from 40 - 0, but the
-        // reference's fp64 quotient carries a rounding noise of up to ~(win^2) ulps of 40 (2e-11 for a 35 x 35 window), so among
-        // candidates closer than that its first minimum is decided by that noise and has to be recomputed
-        const u64 bl = kl[x];
-        if (bl != KEY_NONE && (int)(uint32_t)bl != d && exact_near(key, (uint32_t)(bl >> 32), A.tol, A.sat_abs)) sides |= EXACT_SIDE_L;
-        if (kr) {
-            const u64 br = kr[x - d];
-            if (br != KEY_NONE && (int)(uint32_t)br != x && exact_near(key, (uint32_t)(br >> 32), A.tol, A.sat_abs)) sides |= EXACT_SIDE_R;
-        }
-        if (!sides) continue;
-        const uint32_t pix = (uint32_t)yr * (uint32_t)A.W + (uint32_t)x;
-        if (sides & EXACT_SIDE_L) A.flagL[pix] = 1;
-        if (sides & EXACT_SIDE_R) A.flagR[pix - (uint32_t)d] = 1;
-        const unsigned slot = atomicAdd(A.counter, 1u);
-        if (slot < A.cap) A.entries[slot] = exact_entry(pix, d, sides);
-    }
-}
-
-// ... and the winners of the flagged pixels themselves
+// 2. the winners of the flagged pixels join their near-ties in the queue; their result slots are initialised here (only
+// flagged pixels have entries, so nothing else is ever read: no 24 B / pixel memset)
 __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactArgs A)
 {
+    const AswExactQueue &Q = A.q;
     const long long n = (long long)A.rows * A.W;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
-        if (A.flagL[q]) {
-            atomicAdd(A.counter + 1, 1u);
-            const unsigned slot = atomicAdd(A.counter, 1u);
-            if (slot < A.cap) A.entries[slot] = exact_entry((uint32_t)q, (int)(uint32_t)A.keyL[q], EXACT_SIDE_L);
+    for (long long q0 = (long long)blockIdx.x * blockDim.x; q0 < n; q0 += (long long)gridDim.x * blockDim.x) {
+        const long long q = q0 + threadIdx.x;
+        const bool inb = q < n;
+        const bool fl = inb && Q.flagL[q];
+        if (fl) {
+            A.costL[q] = ~0ull;
+            A.idxL[q] = 0xffffffffu;
         }
-        if (A.keyR && A.flagR[q]) {
-            atomicAdd(A.counter + 2, 1u);
-            const int xr = (int)(q % A.W), xl = (int)(uint32_t)A.keyR[q];
-            const unsigned slot = atomicAdd(A.counter, 1u);
-            if (slot < A.cap) A.entries[slot] = exact_entry((uint32_t)(q + (xl - xr)), xl - xr, EXACT_SIDE_R);
+        const int dwin = fl ? (A.keyL ? (int)(uint32_t)A.keyL[q] : (int)A.disp[q]) : 0;
+        const u64 ml = __builtin_amdgcn_ballot_w64(fl);
+        if (ml && fl && (int)__builtin_ctzll(ml) == (int)(threadIdx.x & 63)) atomicAdd(Q.counter + 1, (unsigned)__builtin_popcountll(ml));
+        asw_exact_push_wave(Q, fl, (uint32_t)q, dwin, EXACT_SIDE_L);
+        if (A.keyR) {
+            const bool fr = inb && Q.flagR[q];
+            int xl = 0, xr = 0;
+            if (fr) {
+                A.costR[q] = ~0ull;
+                A.idxR[q] = 0xffffffffu;
+                xr = (int)(q % A.W);
+                xl = (int)(uint32_t)A.keyR[q];
+            }
+            const u64 mr = __builtin_amdgcn_ballot_w64(fr);
+            if (mr && fr && (int)__builtin_ctzll(mr) == (int)(threadIdx.x & 63)) atomicAdd(Q.counter + 2, (unsigned)__builtin_popcountll(mr));
+            asw_exact_push_wave(Q, fr, (uint32_t)(q + (xl - xr)), xl - xr, EXACT_SIDE_R);
         }
     }
 }
@@ -168,10 +124,11 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
     __shared__ double s_w[EXACT_WAVES][256], s_c[EXACT_WAVES][256];       // (winSize <= 255)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *const sw = s_w[wv], *const sc = s_c[wv];
-    const unsigned n = min(A.counter[0], A.cap);
+    if (A.q.counter[0] > A.q.cap) return;          // queue overflow: incomplete candidate sets, the fp32 map is kept (asw_exact_patch_kernel)
+    const unsigned n = A.q.counter[0];
     const int W = A.W, H = A.H, win = A.win, p = A.pad;
     for (unsigned e = blockIdx.x * EXACT_WAVES + wv; e < n; e += gridDim.x * EXACT_WAVES) {
-        const u64 ent = A.entries[e];
+        const u64 ent = A.q.entries[e];
         const uint32_t pix = (uint32_t)ent;
         const int d = (int)((ent >> 32) & 0xffff);
         const unsigned sides = (unsigned)(ent >> 48) & 3u;
@@ -225,9 +182,10 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
 // 4. the first minimum wins: smallest disparity (left-referenced), smallest left column (right-referenced)
 __global__ __launch_bounds__(256) void asw_exact_resolve_kernel(const AswExactArgs A)
 {
-    const unsigned n = min(A.counter[0], A.cap);
+    if (A.q.counter[0] > A.q.cap) return;
+    const unsigned n = A.q.counter[0];
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const u64 ent = A.entries[e];
+        const u64 ent = A.q.entries[e];
         const uint32_t pix = (uint32_t)ent;
         const int d = (int)((ent >> 32) & 0xffff);
         const unsigned sides = (unsigned)(ent >> 48) & 3u;
@@ -237,14 +195,17 @@ __global__ __launch_bounds__(256) void asw_exact_resolve_kernel(const AswExactAr
     }
 }
 
-// 5. flagged pixels whose every candidate made it into the queue get the fp64 winner's index in their key
+// 5. flagged pixels whose every candidate made it into the queue get the fp64 winner's index: in their key, or in the map itself
 __global__ __launch_bounds__(256) void asw_exact_patch_kernel(const AswExactArgs A)
 {
-    if (A.counter[0] > A.cap) return;        // queue overflow (counted; the caller reports it): incomplete candidate sets, keys stay as they are
+    if (A.q.counter[0] > A.q.cap) return;        // queue overflow (counted; the caller reports it): incomplete candidate sets, the map stays as it is
     const long long n = (long long)A.rows * A.W;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
-        if (A.flagL[q] && A.idxL[q] != 0xffffffffu) A.keyL[q] = (A.keyL[q] & 0xffffffff00000000ull) | (u64)A.idxL[q];
-        if (A.keyR && A.flagR[q] && A.idxR[q] != 0xffffffffu) A.keyR[q] = (A.keyR[q] & 0xffffffff00000000ull) | (u64)A.idxR[q];
+        if (A.q.flagL[q] && A.idxL[q] != 0xffffffffu) {
+            if (A.keyL) A.keyL[q] = (A.keyL[q] & 0xffffffff00000000ull) | (u64)A.idxL[q];
+            else A.disp[q] = (int16_t)A.idxL[q];
+        }
+        if (A.keyR && A.q.flagR[q] && A.idxR[q] != 0xffffffffu) A.keyR[q] = (A.keyR[q] & 0xffffffff00000000ull) | (u64)A.idxR[q];
     }
 }
 

@@ -62,6 +62,18 @@ struct AswGeom {
     int lds_bytes_evol;          // phase-shifted kernel with the pre-computed TAD volume: LDS without the staged colour bytes (bgrL / bgrR are last)
 };
 
+// exact mode (round 6): the aggregation kernels select the NEAR-TIES of their winners themselves, in the epilogue, and append them
+// to a queue that the fp64 tie-break pass (asw_exact_kernels.hip.h) re-evaluates in the reference's arithmetic -- no cost-image
+// volume in HBM (round 5 dumped H*W*nD*4 bytes and re-read them: 1.6 GB at 1080p / 193, 9.1 GB at 4K).  entries == nullptr: off.
+struct AswExactQueue {
+    u64 *entries;                // pix (32) | d (16) << 32 | sides (2) << 48; pix = (output row - row0) * W + LEFT column
+    unsigned int *counter;       // [0] entries appended (may exceed cap), [1] flagged left pixels, [2] flagged right pixels
+    unsigned char *flagL, *flagR;    // [rows][W] the pixel has near-ties (flagR may be null: no right-referenced pass)
+    unsigned int cap;
+    uint32_t tol;                // cost-image ulps
+    float sat_abs;               // absolute cost difference below which two saturated candidates are a near-tie of the reference's fp64
+};
+
 struct AswArgs {
     const PixRec *recL, *recR;   // [H][W] pixel records of the (sub-)image
     const float *prox;           // [win*win] proximity weights exp(-|t|/gammaP)
@@ -81,6 +93,7 @@ struct AswArgs {
     int yskip_at, yskip;         // ... + yskip for b >= yskip_at: TWO row ranges in one launch (the border rows of a row strip whose
                                  //     interior rows ran while the halo was in flight, strips.py); yskip = 0: one range
     float kC;                    // -log2(e)/gammaC
+    AswExactQueue xq;            // exact mode: near-tie queue (entries == nullptr: off)
     AswGeom g;
 };
 
@@ -153,6 +166,130 @@ __device__ __forceinline__ uint32_t asw_cost_key(const float n, const float s, f
     const float inv = ASW_TAD_CAP * s / t40;
     cost = ASW_TAD_CAP - inv;
     return 0xC0000000u - __float_as_uint(inv);
+}
+
+// ---- exact mode: near-tie selection (shared by the four kernel families) ------------------------------------------------
+static constexpr unsigned EXACT_SIDE_L = 1u, EXACT_SIDE_R = 2u;
+// cost images (asw_cost_key) at or above this hold 40 - cost (cost > 20)
+static constexpr uint32_t EXACT_KEY_HIGH = 0xC0000000u - 0x41A00000u;      // 0x41A00000 = bits of 20.0f
+
+// is candidate image `key` a near-tie of the better image `kb` (kb <= key)?  (a) within `tol` ulps of it -- or (b), both on the
+// saturated side of the image (cost > 20: the image holds 40 - cost), within `sat_abs` in ABSOLUTE terms: the (N, S') pair
+// resolves 40 - 1e-30 from 40 - 0, but the reference's fp64 quotient carries a rounding noise of up to ~(win^2) ulps of 40
+// (2e-11 for a 35 x 35 window), so among candidates closer than that its first minimum is decided by that noise and has to be
+// recomputed -- or (c) the two lie either side of cost = 20, where the image changes form and ulps do not compare.
+// MONOTONE in kb: near(key, kb) implies near(key, kb') for every kb <= kb' <= key, except where (c) held for kb and kb' is on
+// the other side of 20 -- exact_near_local below closes that gap, so a workgroup may test against its tile-local winner
+// (>= the final one) and queue a superset.
+__device__ __forceinline__ bool exact_near(uint32_t key, uint32_t kb, uint32_t tol, float sat_abs)
+{
+    if (key - kb <= tol) return true;
+    if (key >= EXACT_KEY_HIGH) {
+        const float inv = __uint_as_float(0xC0000000u - key);                                   // 40 - cost of the candidate
+        if (kb >= EXACT_KEY_HIGH) return __uint_as_float(0xC0000000u - kb) - inv <= sat_abs;
+        return (40.0f - inv) - __uint_as_float(kb) <= 20.0f * 1.1920929e-7f * (float)tol;
+    }
+    return false;
+}
+
+// ... against a winner kb' that may still be displaced by a better one: also true when both images are saturated-side and the
+// candidate is inside the band above cost 20 that case (c) spans (a final winner just below 20 would make it a near-tie)
+__device__ __forceinline__ bool exact_near_local(uint32_t key, uint32_t kb, uint32_t tol, float sat_abs)
+{
+    if (exact_near(key, kb, tol, sat_abs)) return true;
+    return kb >= EXACT_KEY_HIGH && __uint_as_float(0xC0000000u - key) >= 20.0f - 20.0f * 1.1920929e-7f * (float)tol;
+}
+
+__device__ __forceinline__ u64 exact_entry(uint32_t pix, int d, unsigned sides)
+{
+    return (u64)pix | ((u64)(uint32_t)d << 32) | ((u64)sides << 48);
+}
+
+// Append (pix, d, sides) for the lanes that `want` it.  Wave-aggregated: ONE atomicAdd on the queue counter per wave and call
+// (a flat or saturated frame makes every candidate a near-tie: per-lane atomics on one address would serialise the whole grid).
+// Every lane that reaches the call takes part; lanes that left the kernel earlier are simply not in the ballot.
+__device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool want, uint32_t pix, int d, unsigned sides)
+{
+    const u64 mask = __builtin_amdgcn_ballot_w64(want);
+    if (mask == 0) return;
+    const int leader = (int)__builtin_ctzll(mask);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(q.counter, (unsigned)__builtin_popcountll(mask));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    if (want) {
+        const unsigned slot = base + (unsigned)__builtin_popcountll(mask & (((u64)1 << lane) - 1));
+        if (slot < q.cap) q.entries[slot] = exact_entry(pix, d, sides);
+        if (sides & EXACT_SIDE_L) q.flagL[pix] = 1;
+        if (sides & EXACT_SIDE_R) q.flagR[pix - (uint32_t)d] = 1;
+    }
+}
+
+// Epilogue step 1 (after the barrier that completes the tile-local winners bL / bR in LDS): every candidate of the thread's
+// register tile that is a near-tie of its pixel's LOCAL winner -- and is not that winner -- is queued.  Local winners are >= the
+// final ones, so this is a superset of the near-ties of the final winners (exact_near_local); what is queued needlessly is
+// re-evaluated in fp64 and loses again.  The keys are recomputed from the
+// accumulators (same instructions, same bits as the ones that went into bL / bR).
+//   bL = &bestL[first column of the thread], bR = &bestR[slot of (first column, first disparity + RD - 1)] or nullptr,
+//   xb / db = first column / disparity of the tile, rowpix = (output row - row0) * W.
+// `live` = the lane holds candidates; EVERY lane of the wave calls this (wave-aggregated queue slots).
+template <int RX, int RD>
+__device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool live, const float (&accN)[RX][RD], const float (&accS)[RX][RD],
+                                                 const u64 *bL, const u64 *bR, int xb, int db, int W, int maxD, uint32_t rowpix)
+{
+    static_assert(RX * RD <= 32, "one bit per candidate of the register tile");
+    uint32_t mL = 0, mR = 0;
+    if (live) {
+#pragma unroll
+        for (int xi = 0; xi < RX; ++xi) {
+            const int x = xb + xi;
+            const u64 kl = bL[xi];
+#pragma unroll
+            for (int di = 0; di < RD; ++di) {
+                const int d = db + di;
+                if (x < W && d <= maxD && x - d >= 0) {
+                    float c;
+                    const uint32_t key = asw_cost_key(accN[xi][di], accS[xi][di], c);
+                    if ((int)(uint32_t)kl != d && exact_near_local(key, (uint32_t)(kl >> 32), q.tol, q.sat_abs)) mL |= 1u << (xi * RD + di);
+                    if (bR) {
+                        const u64 kr = bR[xi - di + RD - 1];
+                        if ((int)(uint32_t)kr != x && exact_near_local(key, (uint32_t)(kr >> 32), q.tol, q.sat_abs)) mR |= 1u << (xi * RD + di);
+                    }
+                }
+            }
+        }
+    }
+    uint32_t m = mL | mR;
+    while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {          // (wave-uniform: as many rounds as the busiest lane has near-ties -- usually none)
+        const bool want = m != 0;
+        const int b = want ? __builtin_ctz(m) : 0;
+        const int xi = b / RD, di = b - xi * RD;
+        const unsigned sides = ((mL >> b) & 1u ? EXACT_SIDE_L : 0u) | ((mR >> b) & 1u ? EXACT_SIDE_R : 0u);
+        asw_exact_push_wave(q, want, rowpix + (uint32_t)(xb + xi), db + di, sides);
+        m &= m - 1;
+    }
+}
+
+// Epilogue step 2: `mine` (a tile-local winner) has just been merged into the pixel's global key with old = atomicMin(&key, mine).
+// Whichever of the two loses is queued if it is a near-tie of the other: atomics on one address are totally ordered, every
+// local winner meets the running minimum exactly once, and the running minimum is >= the final one -- so every local winner
+// that is a near-tie of the FINAL winner is queued, by its own workgroup or by the one that displaced it; the final winner
+// itself never is (asw_exact_winners_kernel adds it for flagged pixels).  RIGHT: keys of a right pixel xcol, low word = left column.
+template <bool RIGHT>
+__device__ __forceinline__ void asw_exact_merge(const AswExactQueue &q, bool have, u64 mine, u64 old, uint32_t rowpix, int xcol)
+{
+    bool want = false;
+    uint32_t pix = 0;
+    int d = 0;
+    if (have && old != KEY_NONE) {
+        const u64 lo = mine < old ? mine : old, hi = mine < old ? old : mine;
+        if (exact_near_local((uint32_t)(hi >> 32), (uint32_t)(lo >> 32), q.tol, q.sat_abs)) {
+            want = true;
+            if (RIGHT) { const int xl = (int)(uint32_t)hi; pix = rowpix + (uint32_t)xl; d = xl - xcol; }
+            else { pix = rowpix + (uint32_t)xcol; d = (int)(uint32_t)hi; }
+        }
+    }
+    asw_exact_push_wave(q, want, pix, d, RIGHT ? EXACT_SIDE_R : EXACT_SIDE_L);
 }
 
 // wL / wR rows are stored with their even and odd 16-byte blocks in two halves ("parity split"):
@@ -518,11 +655,37 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     }
     __syncthreads();
     const size_t orow = (size_t)(y - A.row0) * W;
+    const bool xq = !WITH_COSTS && A.xq.entries != nullptr;          // exact mode: near-ties of the winners go to the fp64 pass's queue
+    if (xq) {
+        const bool live = tidf < g.XG * g.DG;
+        const int xg = live ? tidf % g.XG : 0, dg = live ? tidf / g.XG : 0;
+        asw_exact_select<RX, ASW_RD>(A.xq, live, accN, accS, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
+                                     x0 + RX * xg, dlo + ASW_RD * dg, W, A.maxD, (uint32_t)orow);
+    }
     if (A.disp) {
         for (int k = tid; k < Tx; k += nthr) {
             const int x = x0 + k;
             if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
         }
+        return;
+    }
+    if (xq) {
+        // tile-local winners meet the pixels' running minima: the loser of each meeting is queued if it is a near-tie (uniform trip counts)
+        for (int k0 = 0; k0 < Tx; k0 += nthr) {
+            const int k = k0 + tid, x = x0 + k;
+            const bool have = k < Tx && x < W && bestL[k < Tx ? k : 0] != KEY_NONE;
+            const u64 mine = have ? bestL[k] : KEY_NONE;
+            const u64 old = have ? atomicMin(&A.keyL[orow + x], mine) : KEY_NONE;
+            asw_exact_merge<false>(A.xq, have, mine, old, (uint32_t)orow, x);
+        }
+        if (A.keyR)
+            for (int k0 = 0; k0 < nRc; k0 += nthr) {
+                const int k = k0 + tid, xr = xrc_lo + k;
+                const bool have = k < nRc && (unsigned)xr < (unsigned)W && bestR[k < nRc ? k : 0] != KEY_NONE;
+                const u64 mine = have ? bestR[k] : KEY_NONE;
+                const u64 old = have ? atomicMin(&A.keyR[orow + xr], mine) : KEY_NONE;
+                asw_exact_merge<true>(A.xq, have, mine, old, (uint32_t)orow, xr);
+            }
         return;
     }
     for (int k = tid; k < Tx; k += nthr) {

@@ -601,11 +601,36 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     }
     __syncthreads();
     const size_t orow = (size_t)(y - A.row0) * W;
+    const bool xq = !WITH_COSTS && A.xq.entries != nullptr;          // exact mode: near-ties of the winners go to the fp64 pass's queue
+    if (xq) {
+        const int xg = pk_xd & 0xffff, dg = pk_xd >> 16;
+        asw_exact_select<RX, ASW_RD>(A.xq, tidf < nact, accN, accS, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
+                                     x0 + RX * xg, dlo + ASW_RD * dg, W, A.maxD, (uint32_t)orow);
+    }
     if (A.disp) {
         for (int k = tid; k < Tx; k += nthr) {
             const int x = x0 + k;
             if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
         }
+        return;
+    }
+    if (xq) {
+        // tile-local winners meet the pixels' running minima: the loser of each meeting is queued if it is a near-tie (uniform trip counts)
+        for (int k0 = 0; k0 < Tx; k0 += nthr) {
+            const int k = k0 + tid, x = x0 + k;
+            const bool have = k < Tx && x < W && bestL[k < Tx ? k : 0] != KEY_NONE;
+            const u64 mine = have ? bestL[k] : KEY_NONE;
+            const u64 old = have ? atomicMin(&A.keyL[orow + x], mine) : KEY_NONE;
+            asw_exact_merge<false>(A.xq, have, mine, old, (uint32_t)orow, x);
+        }
+        if (A.keyR)
+            for (int k0 = 0; k0 < nRc; k0 += nthr) {
+                const int k = k0 + tid, xr = xrc_lo + k;
+                const bool have = k < nRc && (unsigned)xr < (unsigned)W && bestR[k < nRc ? k : 0] != KEY_NONE;
+                const u64 mine = have ? bestR[k] : KEY_NONE;
+                const u64 old = have ? atomicMin(&A.keyR[orow + xr], mine) : KEY_NONE;
+                asw_exact_merge<true>(A.xq, have, mine, old, (uint32_t)orow, xr);
+            }
         return;
     }
     for (int k = tid; k < Tx; k += nthr) {

@@ -285,11 +285,34 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
         }
     }
     asw_wave_sync();
+    const bool xq = !WITH_COSTS && A.xq.entries != nullptr;          // exact mode: near-ties of the winners go to the fp64 pass's queue
+    if (xq)
+        asw_exact_select<RX, RD>(A.xq, active, accN, accS, bestL + RX * xg, A.keyR ? bestR + (RX * xg - RD * dg + Dc - RD) : nullptr,
+                                 x0 + RX * xg, dlo + RD * dg, W, A.maxD, (uint32_t)orow);
     if (A.disp) {
         for (int k = lane; k < Txw; k += 64) {
             const int x = x0 + k;
             if (x < W) A.disp[orow + x] = bestL[k] == KEY_NONE ? (int16_t)x : (int16_t)(uint32_t)bestL[k];
         }
+        return;
+    }
+    if (xq) {
+        // strip-local winners meet the pixels' running minima: the loser of each meeting is queued if it is a near-tie
+        for (int k0 = 0; k0 < Txw; k0 += 64) {
+            const int k = k0 + lane, x = x0 + k;
+            const bool have = k < Txw && x < W && bestL[k < Txw ? k : 0] != KEY_NONE;
+            const u64 mine = have ? bestL[k] : KEY_NONE;
+            const u64 old = have ? atomicMin(&A.keyL[orow + x], mine) : KEY_NONE;
+            asw_exact_merge<false>(A.xq, have, mine, old, (uint32_t)orow, x);
+        }
+        if (A.keyR)
+            for (int k0 = 0; k0 < nRcw; k0 += 64) {
+                const int k = k0 + lane, xr = xrc_lo + k;
+                const bool have = k < nRcw && (unsigned)xr < (unsigned)W && bestR[k < nRcw ? k : 0] != KEY_NONE;
+                const u64 mine = have ? bestR[k] : KEY_NONE;
+                const u64 old = have ? atomicMin(&A.keyR[orow + xr], mine) : KEY_NONE;
+                asw_exact_merge<true>(A.xq, have, mine, old, (uint32_t)orow, xr);
+            }
         return;
     }
     for (int k = lane; k < Txw; k += 64) {

@@ -911,50 +911,64 @@ int get_prox64(Ctx &c, int win, double gammaP, hipStream_t s, const double **out
     return SSAMD_OK;
 }
 
-// fp64 tie-break pass (asw_exact_kernels.hip.h) between the aggregation and the finalisation of an ASW call: c.costs holds the
-// cost images of every candidate, c.keyL / c.keyR the fp32 winners.  Rewrites the low words of the keys of pixels whose
-// near-ties fp64 decides differently.
-int asw_exact_pass(Ctx &c, int H, int W, int row0, int rows, int win, int maxD, int minD, double gammaC, double gammaP,
-                   bool consistent, hipStream_t s)
+// fp64 tie-break pass (asw_exact_kernels.hip.h), part 1 -- BEFORE the aggregation: queue, pixel flags and counters of this call;
+// fills the AswExactQueue the aggregation kernels append their near-ties to (round 6: no cost-image volume).
+int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, bool consistent, hipStream_t s, AswExactQueue &q)
 {
-    const int nD = maxD - minD + 1, p = win / 2;
-    const size_t nout = (size_t)rows * W, npix = (size_t)H * W;
+    const size_t nout = (size_t)rows * W;
     if (nout >= ((size_t)1 << 32)) return fail(SSAMD_ELIMIT, "exact mode: more than 2^32 output pixels per call");
+    // queue: room for a few candidates of every pixel, bounded (a frame of saturated noise can flag every candidate of every
+    // pixel; an overflow leaves the fp32 map and is reported: `exact_overflow`); frames of up to 4M candidates in all get room
+    // for every one of them -- a flat test image cannot overflow
+    size_t cap = std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(nout * (size_t)nD + nout, (size_t)1 << 22)), (size_t)1 << 25);
+    if (tune().exact_cap) cap = (size_t)tune().exact_cap;
+    int rc;
+    // [64 B counters][flagL nout][flagR nout]: one buffer, one memset
+    if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(64 + 2 * nout)) ||
+        (rc = c.xslots.reserve(nout * 24)))
+        return rc;
+    c.xcap = (unsigned int)cap;
+    HIP_TRY(hipMemsetAsync(c.xflags.ptr, 0, 64 + (consistent ? 2 : 1) * nout, s));
+    q.entries = (u64 *)c.xqueue.ptr;
+    q.counter = (unsigned int *)c.xflags.ptr;
+    q.flagL = (unsigned char *)c.xflags.ptr + 64;
+    q.flagR = consistent ? q.flagL + nout : nullptr;
+    q.cap = (unsigned int)cap;
+    // Near-tie band.  128 ulps = 1.5e-5 relative at gammaC = 5 and a 35 x 35 window: the kernels' support weights inherit the
+    // rounding of the Lab records to float (|dLab| <= ~1.3e-5 per colour distance), i.e. a relative error of ~2.6e-5 / gammaC on a
+    // weight product -- scaled up for smaller gammaC; and the (N, S') sums are fp32 sums of win^2 products whose rounding errors
+    // add up like a random walk (~win ulps): scaled up with the window beyond 35 (a fixed band ignored the tap
+    // count; tests/test_gpu_exact.py::test_large_windows_against_the_oracle)
+    q.tol = (uint32_t)std::min(1.0e6, (double)tune().exact_tol * std::max(1.0, 5.0 / gammaC) * std::max(1.0, win / 35.0));
+    // rounding noise of the reference's fp64 quotient sum(w e) / sum(w) over n = win^2 taps: <= ~(n + 3) u relative on numerator and
+    // denominator each, u = 2^-53, i.e. 2 (n + 3) u 40 absolute near the cap; two candidates can swap places when they are
+    // closer than twice that (x 1.5 margin)
+    q.sat_abs = (float)(1.5 * 2.0 * 2.0 * ((double)win * win + 3.0) * 1.1102230246251565e-16 * 40.0);
+    return SSAMD_OK;
+}
+
+// ... part 2 -- AFTER the aggregation: the queue holds the near-ties of every winner, c.keyL / c.keyR (or the map itself when the
+// aggregation wrote it: `direct`) the fp32 winners.  Rewrites the winners of pixels whose near-ties fp64 decides differently.
+int asw_exact_pass(Ctx &c, const AswExactQueue &q, int H, int W, int row0, int rows, int win, int maxD, int minD, double gammaC, double gammaP,
+                   bool consistent, bool direct, int16_t *d_disp, hipStream_t s)
+{
+    const int p = win / 2;
+    const size_t nout = (size_t)rows * W, npix = (size_t)H * W;
     int rc;
     const double *d_prox = nullptr;
     if ((rc = get_prox64(c, win, gammaP, s, &d_prox))) return rc;
     if ((rc = c.xlabL.reserve(npix * 24)) || (rc = c.xlabR.reserve(npix * 24))) return rc;
-    // queue: room for a few candidates of every pixel, bounded (a frame of saturated noise can flag every candidate of every
-    // pixel: those entries all evaluate to the same cost and the smallest index wins anyway; an overflow leaves the fp32 map)
-    // (frames of up to 4M candidates in all get room for every one of them: a flat test image cannot overflow)
-    size_t cap = std::min<size_t>(std::max<size_t>(4 * nout, std::min<size_t>(nout * (size_t)nD + nout, (size_t)1 << 22)), (size_t)1 << 25);
-    if (tune().exact_cap) cap = (size_t)tune().exact_cap;
-    if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(2 * nout)) ||
-        (rc = c.xslots.reserve(nout * 24)) || (rc = c.xctr.reserve(64)))
-        return rc;
-    c.xcap = (unsigned int)cap;
-    HIP_TRY(hipMemsetAsync(c.xflags.ptr, 0, 2 * nout, s));
-    HIP_TRY(hipMemsetAsync(c.xslots.ptr, 0xFF, nout * 24, s));
-    HIP_TRY(hipMemsetAsync(c.xctr.ptr, 0, 64, s));
     AswExactArgs x;
     x.recL = (const PixRec *)c.recL.ptr; x.recR = (const PixRec *)c.recR.ptr;
     x.labL = (const double *)c.xlabL.ptr; x.labR = (const double *)c.xlabR.ptr;
     x.prox = d_prox;
-    x.kvol = (const uint32_t *)c.costs.ptr;
-    x.keyL = (u64 *)c.keyL.ptr; x.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
-    x.flagL = (unsigned char *)c.xflags.ptr; x.flagR = x.flagL + nout;
-    x.entries = (u64 *)c.xqueue.ptr; x.counter = (unsigned int *)c.xctr.ptr; x.cap = (unsigned int)cap;
+    x.keyL = direct ? nullptr : (u64 *)c.keyL.ptr; x.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
+    x.disp = d_disp;
+    x.q = q;
     x.ecost = (double *)c.xcost.ptr;
     x.costL = (u64 *)c.xslots.ptr; x.costR = x.costL + nout;
     x.idxL = (uint32_t *)(x.costR + nout); x.idxR = x.idxL + nout;
     x.H = H; x.W = W; x.win = win; x.pad = p; x.minD = minD; x.maxD = maxD; x.row0 = row0; x.rows = rows;
-    // 128 ulps = 1.5e-5 relative at gammaC = 5: the kernels' support weights inherit the rounding of the Lab records to float
-    // (|dLab| <= ~1.3e-5 per colour distance), i.e. a relative error of ~2.6e-5 / gammaC on a weight product -- scaled up for smaller gammaC
-    x.tol = (uint32_t)std::min(1.0e6, (double)tune().exact_tol * std::max(1.0, 5.0 / gammaC));
-    // rounding noise of the reference's fp64 quotient sum(w e) / sum(w) over n = win^2 taps: <= ~(n + 3) u relative on numerator and
-    // denominator each, u = 2^-53, i.e. 2 (n + 3) u 40 absolute near the cap; two candidates can swap places when they are
-    // closer than twice that (x 1.5 margin)
-    x.sat_abs = (float)(1.5 * 2.0 * 2.0 * ((double)win * win + 3.0) * 1.1102230246251565e-16 * 40.0);
     x.gammaC = gammaC;
     Timed t(c, s, SSAMD_K_ASW_EXACT);
     {
@@ -964,9 +978,6 @@ int asw_exact_pass(Ctx &c, int H, int W, int row0, int rows, int win, int maxD, 
         hipLaunchKernelGGL(bgr2lab_f64_pair_kernel, dim3(blocks), dim3(256), 0, s, x.recL + (size_t)r0 * W, x.recR + (size_t)r0 * W,
                            (double *)c.xlabL.ptr + 3 * (size_t)r0 * W, (double *)c.xlabR.ptr + 3 * (size_t)r0 * W, np2);
     }
-    const long long per_row = (long long)W * nD;
-    const int fx = (int)std::min<long long>((per_row + 255) / 256, 64);
-    hipLaunchKernelGGL(asw_exact_flag_kernel, dim3(fx, rows), dim3(256), 0, s, x);
     const int pb = (int)std::min<long long>(((long long)nout + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(asw_exact_winners_kernel, dim3(pb), dim3(256), 0, s, x);
     hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 4), dim3(64 * EXACT_WAVES), 0, s, x);
@@ -1014,16 +1025,11 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     int rc = check_common(H, W, win, minD, maxD, row0, rows);
     if (rc) return rc;
     if (skip < 0 || skip_at < 0 || skip_at + skip > rows) return fail(SSAMD_EINVAL, "bad row gap [%d,%d) in a range of %d rows", skip_at, skip_at + skip, rows);
-    if (skip > 0 && (alternate || exact || d_costs || d_raw_right)) return fail(SSAMD_EINVAL, "two row ranges: plain and consistent matching only");
+    if (skip > 0 && (alternate || d_costs || d_raw_right)) return fail(SSAMD_EINVAL, "two row ranges: plain, consistent and exact matching only");
     if (skip == rows) return SSAMD_OK;
     if (!(gammaC > 0) || !(gammaP > 0)) return fail(SSAMD_EINVAL, "gammaC and gammaP must be positive");
     if (exact && (alternate || d_costs)) return fail(SSAMD_EINVAL, "the exact (fp64 tie-break) mode has no alternate-rows form and no cost dump");
     if (maxD < minD) exact = false;                                   // empty candidate loops: nothing to break ties between
-    if (exact) {
-        // the aggregation kernels dump the cost image of every candidate into c.costs (their verification dump, keys instead of floats)
-        if ((rc = c.costs.reserve((size_t)rows * W * (size_t)(maxD - minD + 1) * 4))) return rc;
-        d_costs = (float *)c.costs.ptr;
-    }
     // alternate-rows mode: row0 is matched exactly, then every second row; the range must end with an exact row or with
     // the image (asw_alternate_rows arranges that for strips)
     if (alternate && d_costs) return fail(SSAMD_EINVAL, "the alternate-rows mode has no cost dump");
@@ -1044,7 +1050,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     std::vector<AswGeom> trial;
     const double call_taps = (double)W * grows * nD * win * win;
     const int tune_mode = g_autotune.load();
-    const bool tune_now = (tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS)) && !exact;   // (trial launches would all dump)
+    const bool tune_now = (tune_mode > 0 || (tune_mode < 0 && call_taps <= ASW_AUTOTUNE_SMALL_TAPS));
     bool tuned_already;
     { std::lock_guard<std::mutex> glk(g_geom_mutex); tuned_already = g_asw_geom_tuned.count(shape) != 0; }
     if (tune_now && nD >= 1 && !asw_geometry_forced() && !tuned_already) {
@@ -1082,7 +1088,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     if (nD >= 1 && !wave_volume_fits(a.g)) a.g.wave_rx = 0;
     trial.erase(std::remove_if(trial.begin(), trial.end(), [&](const AswGeom &g) { return !wave_volume_fits(g); }), trial.end());
     if (trial.size() < 2) trial.clear();
-    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent && !exact; };   // (the tie-break pass patches keys)
+    auto is_direct = [&](const AswGeom &g) { return nD >= 1 && (g.nchunks == 1 || g.wave_rx) && !consistent; };
     bool need_keys = !is_direct(a.g) || alternate;  // the alternate mode merges its odd-row jobs through the left keys
     for (const AswGeom &g : trial) need_keys = need_keys || !is_direct(g);
     if (need_keys) {
@@ -1123,7 +1129,8 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
         a.prox = d_prox;
         a.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
         a.costs = d_costs;
-        a.cost_keys = exact ? 1 : 0;
+        a.cost_keys = 0;
+        a.xq = AswExactQueue{};                                       // (the autotuner's trial launches run without the queue)
         a.H = H; a.W = W; a.win = win; a.pad = p; a.minD = minD; a.maxD = maxD; a.row0 = row0; a.rows = rows;
         a.kC = (float)(-1.4426950408889634 / gammaC);
         a.ystep = alternate ? 2 : 1;
@@ -1214,7 +1221,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
             a.disp = is_direct(g) ? d_disp : nullptr;
             if (g.wave_rx) {                  // (prepare_evol(g) filled wa.g and built the volume)
                 wa.recL = a.recL; wa.recR = a.recR; wa.prox = a.prox;
-                wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs; wa.cost_keys = a.cost_keys;
+                wa.keyL = a.keyL; wa.keyR = a.keyR; wa.disp = a.disp; wa.costs = a.costs; wa.cost_keys = a.cost_keys; wa.xq = a.xq;
                 wa.evol = a.evol; wa.erow0 = a.erow0; wa.erows = a.erows; wa.evolW = a.evolW;
                 wa.H = H; wa.W = W; wa.win = win; wa.pad = p; wa.minD = minD; wa.maxD = maxD; wa.row0 = row0; wa.rows = rows;
                 wa.ystep = a.ystep; wa.kC = a.kC; wa.yb0 = 0; wa.yskip_at = a.yskip_at; wa.yskip = a.yskip;
@@ -1399,12 +1406,23 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 lab_pending = false;
                 if ((rc = launch_lab())) return rc;
             }
+            if (exact) {
+                if (!trial.empty()) {
+                    // the trial launches of the autotuner merged their winners into the keys: start the final launch from clean
+                    // ones, or its tile-local winners would meet their own copies (asw_exact_merge)
+                    if (need_keys) HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
+                    if (consistent) HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
+                }
+                if ((rc = asw_exact_prepare(c, W, rows, win, nD, gammaC, consistent != 0, s, a.xq))) return rc;
+            }
             Timed t(c, s, SSAMD_K_ASW_AGG);
             if ((rc = launch(final_geom))) return rc;
         }
     }
     const bool direct = is_direct(a.g);
-    if (exact && (rc = asw_exact_pass(c, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent != 0, s))) return rc;
+    if (exact && nD >= 1 &&
+        (rc = asw_exact_pass(c, a.xq, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent != 0, direct, d_disp, s)))
+        return rc;
     if (!direct && skip > 0) {
         // decode / left-right check of the two bands only (row-local: _passive.cpp:251-285); the rows between keep what the
         // interior call wrote
@@ -1924,10 +1942,10 @@ int ssamd_device_count(void)
 
 const char *ssamd_kernel_name(int slot)
 {
-    static const char *names[SSAMD_K_COUNT] = {"bgr2lab_records_pair_kernel + asw_tad_volume_kernel", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
+    static const char *names[SSAMD_K_COUNT] = {"asw pre-pass (asw_prepass_kernel: Lab records + TAD volume; or bgr2lab_records_pair_kernel, asw_tad_volume_kernel)", "asw aggregation kernel (asw_aggregate_pipe / _wave / asw_aggregate_kernel)",
                                                "asw finalize (wta_decode / lr_check_fill)",
                                                "gsw_aggregate_kernel", "gsw finalize (lr_check_fill)", "remap_bgr_kernel", "reproject_kernel",
-                                               "asw_alt_fill_kernel", "asw fp64 tie-break pass (asw_exact_* kernels)"};
+                                               "asw_alt_fill_kernel", "asw fp64 tie-break pass (bgr2lab_f64_pair + asw_exact_winners / _eval / _resolve / _patch kernels)"};
     return (slot >= 0 && slot < SSAMD_K_COUNT) ? names[slot] : "";
 }
 
@@ -1964,9 +1982,9 @@ int ssamd_counter(int device, const char *name, long long *value)
     else if (n == "exact_entries" || n == "exact_flagged_left" || n == "exact_flagged_right" || n == "exact_overflow") {
         // of the LAST exact call on this device: candidates re-evaluated in fp64, pixels with near-ties, whether the queue overflowed
         unsigned int ctr[3] = {0, 0, 0};
-        if (c->xctr.ptr) {
+        if (c->xflags.ptr && c->exact_calls > 0) {       // (the counters are the first 64 bytes of the flag buffer: one memset per call)
             HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipMemcpy(ctr, c->xctr.ptr, sizeof(ctr), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ctr, c->xflags.ptr, sizeof(ctr), hipMemcpyDeviceToHost));
         }
         *value = n == "exact_entries" ? ctr[0] : n == "exact_flagged_left" ? ctr[1] : n == "exact_flagged_right" ? ctr[2] : (ctr[0] > c->xcap ? 1 : 0);
     }
@@ -2065,6 +2083,40 @@ int ssamd_asw_exact_device(const uint8_t *d_img1, const uint8_t *d_img2, int hei
     if (rc) return rc;
     return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
                            gammaC, gammaP, consistent, d_disparity, nullptr, (hipStream_t)stream, false, nullptr, nullptr, true);
+}
+
+int ssamd_asw_exact_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                                 int skip_row0, int skip_rows, int winSize, int maxDisparity, int minDisparity, double gammaC, double gammaP,
+                                 int consistent, int16_t *d_disparity, void *stream)
+{
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    if (skip_rows < 0 || (skip_rows > 0 && (skip_row0 < out_row0 || skip_row0 + skip_rows > out_row0 + out_rows)))
+        return fail(SSAMD_EINVAL, "the skipped rows [%d,%d) must lie inside the output rows [%d,%d)", skip_row0, skip_row0 + skip_rows,
+                    out_row0, out_row0 + out_rows);
+    return asw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity, gammaC, gammaP,
+                           consistent, d_disparity, nullptr, (hipStream_t)stream, false, nullptr, nullptr, true,
+                           skip_rows > 0 ? skip_row0 - out_row0 : 0, skip_rows);
+}
+
+int ssamd_asw_exact_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
+                                     const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
+                                     int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,
+                                     double gammaC, double gammaP, int consistent, int16_t *d_disparity, void *stream)
+{
+    if (!d_raw1 || !d_raw2 || !d_mapx1 || !d_mapy1 || !d_mapx2 || !d_mapy2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (src_height <= 0 || src_width <= 0) return fail(SSAMD_EINVAL, "Wrong image dimensions!");
+    if (interpolation != 0 && interpolation != 1) return fail(SSAMD_EINVAL, "only INTER_NEAREST (0) and INTER_LINEAR (1) are supported");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    RemapSrc rm;
+    rm.src1 = d_raw1; rm.src2 = d_raw2; rm.mapx1 = d_mapx1; rm.mapy1 = d_mapy1; rm.mapx2 = d_mapx2; rm.mapy2 = d_mapy2;
+    rm.Hs = src_height; rm.Ws = src_width; rm.nearest = interpolation == 0 ? 1 : 0;
+    return asw_device_impl(*c, nullptr, nullptr, height, width, 0, height, winSize, maxDisparity, minDisparity, gammaC, gammaP, consistent,
+                           d_disparity, nullptr, (hipStream_t)stream, false, nullptr, &rm, true);
 }
 
 int ssamd_asw_exact(const uint8_t *img1, const uint8_t *img2, int height, int width, int winSize, int maxDisparity,
@@ -2221,7 +2273,6 @@ int ssamd_debug_exact_costs(const uint8_t *img1, const uint8_t *img2, int height
         (rc = c->recR.reserve(npix * sizeof(PixRec))) || (rc = c->xlabL.reserve(npix * 24)) || (rc = c->xlabR.reserve(npix * 24)) ||
         (rc = c->xqueue.reserve((size_t)std::max(n, 1) * 8)) || (rc = c->xcost.reserve((size_t)std::max(n, 1) * 8)) || (rc = c->xctr.reserve(64)))
         return rc;
-    c->xcap = (unsigned int)std::max(n, 1);
     HIP_TRY(hipMemcpyAsync(c->imgL.ptr, img1, npix * 3, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->imgR.ptr, img2, npix * 3, hipMemcpyHostToDevice, s));
     const int blocks = (int)std::min<long long>((2 * (long long)npix + 255) / 256, 256 * 8);
@@ -2243,7 +2294,7 @@ int ssamd_debug_exact_costs(const uint8_t *img1, const uint8_t *img2, int height
     AswExactArgs x{};
     x.recL = (const PixRec *)c->recL.ptr; x.recR = (const PixRec *)c->recR.ptr;
     x.labL = (const double *)c->xlabL.ptr; x.labR = (const double *)c->xlabR.ptr;
-    x.prox = d_prox; x.entries = (u64 *)c->xqueue.ptr; x.counter = (unsigned int *)c->xctr.ptr; x.cap = (unsigned int)std::max(n, 1);
+    x.prox = d_prox; x.q.entries = (u64 *)c->xqueue.ptr; x.q.counter = (unsigned int *)c->xctr.ptr; x.q.cap = (unsigned int)std::max(n, 1);
     x.ecost = (double *)c->xcost.ptr;
     x.H = height; x.W = width; x.win = winSize; x.pad = winSize / 2; x.row0 = 0; x.rows = height; x.gammaC = gammaC;
     hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256), dim3(64 * EXACT_WAVES), 0, s, x);

@@ -221,7 +221,7 @@ class StripContext:
         if mode == "0":
             overlap = False
         self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ == "StereoASW" and
-                            not getattr(matcher, "alternate", False) and not getattr(matcher, "exact", False) and
+                            not getattr(matcher, "alternate", False) and
                             self.world > 1 and self._ops and self.interior > 0 and self.top + self.bot > 0)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self.strip_out = torch.empty((n, self.W), dtype=torch.int16, device=self.device) if self.overlap else None

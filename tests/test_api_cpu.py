@@ -23,18 +23,22 @@ def ss():
 
 def test_signatures_match_reference(ss):
     """passive.py:59 and passive.py:133-134 of the reference; our only additions are trailing keywords
-    (`device=None`, and `alternate=False`, `exact=False` for ASW), so every positional / keyword call of the reference
+    (`device=None`, and `alternate=False`, `exact="auto"` for ASW), so every positional / keyword call of the reference
     binds identically"""
     sig = inspect.signature(ss.passive.StereoASW.__init__)
     assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
         ("winSize", 35), ("maxDisparity", 16), ("minDisparity", 0), ("gammaC", 5), ("gammaP", 17.5),
-        ("consistent", False), ("device", None), ("alternate", False), ("exact", False)]
+        ("consistent", False), ("device", None), ("alternate", False), ("exact", "auto")]
     sig = inspect.signature(ss.passive.StereoGSW.__init__)
     assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
         ("winSize", 11), ("maxDisparity", 16), ("minDisparity", 0), ("gamma", 10), ("fMax", 120),
         ("iterations", 3), ("bins", 20), ("device", None)]
     assert ss.passive.StereoASW()._alternate(0) is False and ss.passive.StereoASW(alternate=True)._alternate(0) is True
-    assert ss.passive.StereoASW()._exact() is False and ss.passive.StereoASW(exact=True)._exact() is True
+    # exact="auto" (round 6): the reference's fp64 argmin by default, off only where it has no form (alternate rows)
+    assert ss.passive.StereoASW()._exact() is True and ss.passive.StereoASW(exact=True)._exact() is True
+    assert ss.passive.StereoASW(exact=False)._exact() is False and ss.passive.StereoASW(alternate=True)._exact() is False
+    with pytest.raises(ValueError):
+        ss.passive.StereoASW(exact="always")._exact()
     with pytest.raises(ValueError):
         ss.passive.StereoASW(exact=True, alternate=True)._exact()
     with pytest.raises(ValueError):

@@ -1,4 +1,4 @@
-"""GPU tier: the opt-in fp64 tie-break pass of StereoASW (`exact=True`, ssamd_asw_exact*; csrc/asw_exact_kernels.hip.h).
+"""GPU tier: the fp64 tie-break pass of StereoASW (`exact=True`, the default since round 6; ssamd_asw_exact*; csrc/asw_exact_kernels.hip.h).
 
 The fp32 kernels may pick the other one of two candidates whose costs agree to ~1e-6 relative; the reference decides
 those in double (reference _passive.cpp:23, 56-95).  With exact=True every candidate within 128 ulps of its pixel's winning
@@ -36,7 +36,7 @@ def _photo(cid):
 def test_exact_mode_on_photographs(cid, bar, ss):
     """P4a (class default on the quarter-size lawn pair) is 99.90 % identical on the fp32 path, P2a / P5a miss 2 / 4 pixels"""
     a, b, p, ref = _photo(cid)
-    d32 = ss.passive.StereoASW(**p).compute(a, b)
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(a, b)
     d64 = ss.passive.StereoASW(exact=True, **p).compute(a, b)
     e32, e64 = float(np.mean(d32 == ref)), float(np.mean(d64 == ref))
     from simplestereo_amd import _native
@@ -56,7 +56,7 @@ def test_exact_mode_on_the_small_goldens(cid, ss, golden_cases, golden_inputs):
     m = meta[cid]
     a, b = golden_inputs(m["input"])
     p = {k: v for k, v in m["params"].items() if k != "algo"}
-    d32 = ss.passive.StereoASW(**p).compute(a, b)
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(a, b)
     d64 = ss.passive.StereoASW(exact=True, **p).compute(a, b)
     n32, n64 = int(np.count_nonzero(d32 != maps[cid])), int(np.count_nonzero(d64 != maps[cid]))
     print("%s: pixels differing from the reference fp32 %d -> exact %d of %d" % (cid, n32, n64, d64.size))
@@ -110,7 +110,7 @@ def test_exact_mode_fuzz_vs_fp64_oracle(seed, ss):
     p = dict(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=float(3 + seed), gammaP=float(6 + 3 * seed))
     d64 = ss.passive.StereoASW(exact=True, **p).compute(L, R)
     bad, ties = _oracle_ties(L, R, p, d64)
-    d32 = ss.passive.StereoASW(**p).compute(L, R)
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(L, R)
     bad32, ties32 = _oracle_ties(L, R, p, d32)
     print("seed %d %dx%d win %d D %d..%d: exact mode %d non-tie + %d tie differences (fp32 path: %d + %d)" %
           (seed, W, H, win, minD, maxD, bad, ties, bad32, ties32))
@@ -129,7 +129,7 @@ def test_exact_mode_consistent_vs_oracle_and_strips(ss):
     d = m.compute(L, R)
     ref = oracle.asw(L, R, **p)
     n = int(np.count_nonzero(d != ref))
-    n32 = int(np.count_nonzero(ss.passive.StereoASW(**p).compute(L, R) != ref))
+    n32 = int(np.count_nonzero(ss.passive.StereoASW(exact=False, **p).compute(L, R) != ref))
     print("consistent exact: %d pixels differ from the oracle (fp32 path %d)" % (n, n32))
     assert n == 0, (n, n32)
     tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
@@ -147,7 +147,7 @@ def test_exact_mode_queue_overflow_keeps_the_fp32_map(ss):
     from simplestereo_amd.synth import make_pair
     L, R, _ = make_pair(48, 160, 32, 5)
     p = dict(winSize=9, maxDisparity=32)
-    d32 = ss.passive.StereoASW(**p).compute(L, R)
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(L, R)
     with _native.options(SSAMD_EXACT_CAP="4"):
         d = ss.passive.StereoASW(exact=True, **p).compute(L, R)
         assert _native.counter("exact_overflow") == 1 and _native.counter("exact_entries") > 4
@@ -169,7 +169,7 @@ def test_exact_mode_argument_errors(ss):
     assert np.array_equal(two, ss.passive.StereoASW(exact=True, maxDisparity=8, winSize=9).compute(L, R))
     # empty candidate loops (maxDisparity < minDisparity): nothing to break ties between, same output as the plain call
     a = ss.passive.StereoASW(exact=True, winSize=5, maxDisparity=3, minDisparity=5).compute(L, R)
-    assert np.array_equal(a, ss.passive.StereoASW(winSize=5, maxDisparity=3, minDisparity=5).compute(L, R))
+    assert np.array_equal(a, ss.passive.StereoASW(exact=False, winSize=5, maxDisparity=3, minDisparity=5).compute(L, R))
 
 
 def test_device_exp_and_powf_are_the_hosts_libm_bit_for_bit():

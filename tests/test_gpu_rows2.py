@@ -51,7 +51,8 @@ def test_two_row_ranges_argument_errors():
     with pytest.raises(ValueError):
         ss.passive.StereoASW(maxDisparity=16, winSize=9)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out, skip=(2, 5))
     with pytest.raises(ValueError):
-        ss.passive.StereoASW(maxDisparity=16, winSize=9, exact=True)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out, skip=(8, 5))
+        ss.passive.StereoASW(maxDisparity=16, winSize=9, alternate=True)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out, skip=(8, 5))
+    # (round 6: exact=True has a two-range form, ssamd_asw_exact_device_rows2 -- covered by the parametrised test above with the default exact="auto")
     with pytest.raises(ValueError):
         ss.passive.StereoASW(maxDisparity=16, winSize=9)._compute_device(tL, tR, out_row0=5, out_rows=30, out=out[:, :50])
 
