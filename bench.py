@@ -705,7 +705,7 @@ def compact_line(full):
 
 def emit(full):
     """Write the complete record to bench_details.json (repo root and gpurun_out/) and to stderr; return the compact line."""
-    blob = json.dumps(full, indent=1, sort_keys=True)
+    blob = json.dumps({k: v for k, v in full.items() if not k.startswith("_")}, indent=1, sort_keys=True)
     paths = [os.path.join(ROOT, "bench_details.json"), os.path.join(ROOT, "gpurun_out", "bench_details.json")]
     if os.environ.get("SSAMD_BENCH_DETAILS"):           # tests point this at a scratch file
         paths = [os.environ["SSAMD_BENCH_DETAILS"]]
@@ -718,7 +718,6 @@ def emit(full):
             pass
     sys.stderr.write("bench_details: " + json.dumps(full) + "\n")
     sys.stderr.flush()
-    full.pop("_frame_width", None)
     line = compact_line(full)
     result = json.dumps(line)
     if len(result) >= LINE_LIMIT:        # never hand the driver a line it cannot parse: drop the optional blocks, keep the contract

@@ -249,6 +249,11 @@ int ssamd_bgr2lab(const uint8_t *img, int height, int width, float *lab, int dev
  * values: which = 0: exp on doubles (reference _passive.cpp:47-50); which = 1: powf(x, (float)(1/3.0)) on floats
  * (headers/colorconversion.hpp:55-65).  Lets a test prove them equal to the host's libm bit for bit. */
 int ssamd_debug_libm(int which, int n, const void *in, void *out);
+/* The near-tie queues of the LAST ssamd_asw_exact* call on the current device: which = 0 the final queue (what was re-evaluated
+ * in fp64), 1 the raw queue of a merging call (several disparity chunks / consistent) with the fp32 cost images in `keys`.
+ * Entry = pix | d << 32 | sides << 48 (pix = (row - out_row0) * width + left column; sides 1 left-, 2 right-referenced).
+ * Copies at most max_n entries; *n = entries appended (may exceed the queue's capacity: overflow). */
+int ssamd_debug_exact_queue(int which, long long max_n, unsigned long long *entries, unsigned int *keys, long long *n);
 
 /* The fp64 cost the tie-break pass computes for each of n candidates (yxd: n triples y, x, d of HOST ints) of a host image pair, and
  * optionally (non-NULL) the fp64 CIELab images [height][width][3] it reads: lets a test compare them with the oracle's bit for bit. */

@@ -104,6 +104,8 @@ def lib():
     L.ssamd_remap_bgr_device.argtypes = [P, I, I, P, P, I, I, I, P, P]
     L.ssamd_reproject_device.restype = I
     L.ssamd_reproject_device.argtypes = [P, I, I, ctypes.POINTER(D), P, P]
+    L.ssamd_debug_exact_queue.restype = I
+    L.ssamd_debug_exact_queue.argtypes = [I, ctypes.c_longlong, P, P, P]
     L.ssamd_debug_libm.restype = I
     L.ssamd_debug_libm.argtypes = [I, I, P, P]
     L.ssamd_debug_exact_costs.restype = I

@@ -67,12 +67,23 @@ struct AswGeom {
 // volume in HBM (round 5 dumped H*W*nD*4 bytes and re-read them: 1.6 GB at 1080p / 193, 9.1 GB at 4K).  entries == nullptr: off.
 struct AswExactQueue {
     u64 *entries;                // pix (32) | d (16) << 32 | sides (2) << 48; pix = (output row - row0) * W + LEFT column
-    unsigned int *counter;       // [0] entries appended (may exceed cap), [1] flagged left pixels, [2] flagged right pixels
-    unsigned char *flagL, *flagR;    // [rows][W] the pixel has near-ties (flagR may be null: no right-referenced pass)
+    uint32_t *ekeys;             // RAW queue only: the fp32 cost image of each entry (what asw_exact_filter_kernel compares with the final winners)
+    unsigned int *counter;       // entries appended (may exceed cap)
+    unsigned char *flagL, *flagR;    // [rows][W] the pixel has near-ties (flagR null: no right-referenced pass; both null: RAW queue)
     unsigned int cap;
     uint32_t tol;                // cost-image ulps
     float sat_abs;               // absolute cost difference below which two saturated candidates are a near-tie of the reference's fp64
+    uint32_t deep;               // RAW queue: images at or above this (40 - cost <= sat_abs: every tap with a weight saturated) are NOT queued --
+                                 //   they can only tie a winner within 2 sat_abs of 40, and such pixels get ALL their candidates from
+                                 //   asw_exact_escalate_kernel.  0xffffffff (direct calls): every valid candidate is tested.
 };
+// Two uses.  DIRECT calls (one disparity chunk, no right-referenced pass: every pixel is decided by ONE workgroup, whose tile-local
+// winner IS the final one): the kernels append to the final queue and flag the pixels.  MERGING calls (several chunks, consistent):
+// a workgroup only knows its tile-local winners, which are >= the final ones, so what it selects is a SUPERSET -- it goes, with its
+// cost image, to a RAW queue that asw_exact_filter_kernel (asw_exact_kernels.hip.h) re-tests against the final winners once the
+// aggregation kernel is done.  (Measured, config 3 consistent, before `deep`: 8.3e6 raw candidates, 99.4 % of them
+// with 40 - cost == 0 exactly -- on the bench frame 6 ... 29 % of ALL candidates have every tap saturated, and in a tile that does not
+// hold a right pixel's match they all tie the tile's winner.  With `deep` + escalation: profiles/r06_exact_mode_cost.txt.)
 
 struct AswArgs {
     const PixRec *recL, *recR;   // [H][W] pixel records of the (sub-)image
@@ -196,6 +207,10 @@ __device__ __forceinline__ bool exact_near(uint32_t key, uint32_t kb, uint32_t t
 // candidate is inside the band above cost 20 that case (c) spans (a final winner just below 20 would make it a near-tie)
 __device__ __forceinline__ bool exact_near_local(uint32_t key, uint32_t kb, uint32_t tol, float sat_abs)
 {
+    if (key - kb <= tol) return true;
+    // quick reject (the common case of the epilogue scan: a wrong candidate, cost > 20, of a pixel whose winner is well below 20):
+    // cases (b), (c) and the band all need the winner within 20 * 2^-23 * tol <= 2.4 (tol <= 1e6) of cost = 20 or above it
+    if (key < EXACT_KEY_HIGH || kb < 0x418C0000u) return false;          // 0x418C0000 = bits of 17.5f
     if (exact_near(key, kb, tol, sat_abs)) return true;
     return kb >= EXACT_KEY_HIGH && __uint_as_float(0xC0000000u - key) >= 20.0f - 20.0f * 1.1920929e-7f * (float)tol;
 }
@@ -208,7 +223,7 @@ __device__ __forceinline__ u64 exact_entry(uint32_t pix, int d, unsigned sides)
 // Append (pix, d, sides) for the lanes that `want` it.  Wave-aggregated: ONE atomicAdd on the queue counter per wave and call
 // (a flat or saturated frame makes every candidate a near-tie: per-lane atomics on one address would serialise the whole grid).
 // Every lane that reaches the call takes part; lanes that left the kernel earlier are simply not in the ballot.
-__device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool want, uint32_t pix, int d, unsigned sides)
+__device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool want, uint32_t pix, int d, unsigned sides, uint32_t key = 0)
 {
     const u64 mask = __builtin_amdgcn_ballot_w64(want);
     if (mask == 0) return;
@@ -219,54 +234,126 @@ __device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool
     base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
     if (want) {
         const unsigned slot = base + (unsigned)__builtin_popcountll(mask & (((u64)1 << lane) - 1));
-        if (slot < q.cap) q.entries[slot] = exact_entry(pix, d, sides);
-        if (sides & EXACT_SIDE_L) q.flagL[pix] = 1;
-        if (sides & EXACT_SIDE_R) q.flagR[pix - (uint32_t)d] = 1;
+        if (slot < q.cap) {
+            q.entries[slot] = exact_entry(pix, d, sides);
+            if (q.ekeys) q.ekeys[slot] = key;
+        }
+        if ((sides & EXACT_SIDE_L) && q.flagL) q.flagL[pix] = 1;
+        if ((sides & EXACT_SIDE_R) && q.flagR) q.flagR[pix - (uint32_t)d] = 1;
     }
 }
 
 // Epilogue step 1 (after the barrier that completes the tile-local winners bL / bR in LDS): every candidate of the thread's
 // register tile that is a near-tie of its pixel's LOCAL winner -- and is not that winner -- is queued.  Local winners are >= the
-// final ones, so this is a superset of the near-ties of the final winners (exact_near_local); what is queued needlessly is
-// re-evaluated in fp64 and loses again.  The keys are recomputed from the
-// accumulators (same instructions, same bits as the ones that went into bL / bR).
+// final ones, so this is a superset of the near-ties of the final winners (exact_near_local).  kk = the cost images of the register
+// tile as the first epilogue pass computed them (0xffffffff: not a candidate the reference evaluates).
 //   bL = &bestL[first column of the thread], bR = &bestR[slot of (first column, first disparity + RD - 1)] or nullptr,
 //   xb / db = first column / disparity of the tile, rowpix = (output row - row0) * W.
 // `live` = the lane holds candidates; EVERY lane of the wave calls this (wave-aggregated queue slots).
 template <int RX, int RD>
-__device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool live, const float (&accN)[RX][RD], const float (&accS)[RX][RD],
-                                                 const u64 *bL, const u64 *bR, int xb, int db, int W, int maxD, uint32_t rowpix)
+__device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool live, const uint32_t (&kk)[RX][RD],
+                                                 const u64 *bL, const u64 *bR, int xb, int db, uint32_t rowpix)
 {
     static_assert(RX * RD <= 32, "one bit per candidate of the register tile");
+    // Branch-free per candidate (a first form with short-circuit tests compiled to ~300 exec-mask branches per thread, a second one
+    // with a per-candidate slow path cost + 1 ms on a 37 ms launch: a pixel without a good match has most of its candidates on
+    // that path).  Rule (a) of exact_near for every candidate; rules (b), (c) and the local band only for the columns whose local
+    // winner costs 17.5 or more -- one branch per column, skipped by waves that hold no such column.  Invalid candidates carry
+    // 0xffffffff and are masked out, and so are, in a merging call, candidates at or above q.deep (see AswExactQueue).
     uint32_t mL = 0, mR = 0;
     if (live) {
+        const uint32_t tol = q.tol, deep = q.deep;
+        const float ctol = 20.0f * 1.1920929e-7f * (float)tol, sat_abs = q.sat_abs;
+        auto slow = [&](uint32_t key, uint32_t kh) -> uint32_t {             // exact_near_local without its rule (a), as 0 / 1
+            const float inv = __uint_as_float(0xC0000000u - key);
+            const uint32_t khigh = kh >= EXACT_KEY_HIGH ? 1u : 0u;
+            const uint32_t b_ = khigh & (__uint_as_float(0xC0000000u - kh) - inv <= sat_abs ? 1u : 0u);
+            const uint32_t c_ = (khigh ^ 1u) & ((40.0f - inv) - __uint_as_float(kh) <= ctol ? 1u : 0u);
+            const uint32_t band = khigh & (inv >= 20.0f - ctol ? 1u : 0u);
+            return (key >= EXACT_KEY_HIGH ? 1u : 0u) & (b_ | c_ | band);
+        };
 #pragma unroll
         for (int xi = 0; xi < RX; ++xi) {
-            const int x = xb + xi;
             const u64 kl = bL[xi];
+            const uint32_t kh = (uint32_t)(kl >> 32);
+            const uint32_t wd = (uint32_t)kl - (uint32_t)db;                    // winner's disparity relative to the tile (== di for the winner)
+            uint32_t okm = 0;
 #pragma unroll
             for (int di = 0; di < RD; ++di) {
-                const int d = db + di;
-                if (x < W && d <= maxD && x - d >= 0) {
-                    float c;
-                    const uint32_t key = asw_cost_key(accN[xi][di], accS[xi][di], c);
-                    if ((int)(uint32_t)kl != d && exact_near_local(key, (uint32_t)(kl >> 32), q.tol, q.sat_abs)) mL |= 1u << (xi * RD + di);
-                    if (bR) {
-                        const u64 kr = bR[xi - di + RD - 1];
-                        if ((int)(uint32_t)kr != x && exact_near_local(key, (uint32_t)(kr >> 32), q.tol, q.sat_abs)) mR |= 1u << (xi * RD + di);
+                const uint32_t key = kk[xi][di];
+                const uint32_t ok = (key < deep ? 1u : 0u) & (wd != (uint32_t)di ? 1u : 0u);
+                okm |= ok << di;
+                mL |= (ok & (key - kh <= tol ? 1u : 0u)) << (xi * RD + di);
+            }
+            if (kh >= 0x418C0000u && kh != 0xffffffffu) {                       // 17.5f
+#pragma unroll
+                for (int di = 0; di < RD; ++di) mL |= (((okm >> di) & 1u) & slow(kk[xi][di], kh)) << (xi * RD + di);
+            }
+        }
+        if (bR) {
+#pragma unroll
+            for (int k = 0; k < RX + RD - 1; ++k) {
+                const u64 kr = bR[k];
+                const uint32_t kh = (uint32_t)(kr >> 32);
+                const uint32_t wx = (uint32_t)kr - (uint32_t)xb;                // winner's column relative to the tile (== xi for the winner)
+                const bool high = kh >= 0x418C0000u && kh != 0xffffffffu;
+#pragma unroll
+                for (int xi = 0; xi < RX; ++xi) {
+                    const int di = xi + RD - 1 - k;
+                    if (di >= 0 && di < RD) {                                   // (compile time)
+                        const uint32_t key = kk[xi][di];
+                        const uint32_t ok = (key < deep ? 1u : 0u) & (wx != (uint32_t)xi ? 1u : 0u);
+                        uint32_t near = key - kh <= tol ? 1u : 0u;
+                        if (high) near |= slow(key, kh);
+                        mR |= (ok & near) << (xi * RD + di);
                     }
                 }
             }
         }
     }
-    uint32_t m = mL | mR;
-    while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {          // (wave-uniform: as many rounds as the busiest lane has near-ties -- usually none)
-        const bool want = m != 0;
-        const int b = want ? __builtin_ctz(m) : 0;
+    // Queue slots: ONE returning atomic per wave (a first form took one per round of the busiest lane: the round trips, at the end
+    // of a workgroup with nothing to hide them, cost consistent = True 1.7 ms at 1080p).  Per-lane counts n <= 32 are summed over
+    // the lanes below by bit plane: six ballots.
+    const uint32_t m = mL | mR;
+    const uint32_t n = (uint32_t)__builtin_popcount(m);
+    if (__builtin_amdgcn_ballot_w64(n != 0) == 0) return;
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+        const u64 pl = __builtin_amdgcn_ballot_w64((n >> bit) & 1u);
+        before += __builtin_amdgcn_mbcnt_hi((uint32_t)(pl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pl, 0u)) << bit;
+        total += (uint32_t)__builtin_popcountll(pl) << bit;
+    }
+    const u64 active = __builtin_amdgcn_ballot_w64(true);
+    const int leader = (int)__builtin_ctzll(active);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(q.counter, total);
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    unsigned slot = base + before;
+    uint32_t mm = m;
+    while (mm) {
+        const int b = __builtin_ctz(mm);
+        mm &= mm - 1;
         const int xi = b / RD, di = b - xi * RD;
         const unsigned sides = ((mL >> b) & 1u ? EXACT_SIDE_L : 0u) | ((mR >> b) & 1u ? EXACT_SIDE_R : 0u);
-        asw_exact_push_wave(q, want, rowpix + (uint32_t)(xb + xi), db + di, sides);
-        m &= m - 1;
+        const uint32_t pix = rowpix + (uint32_t)(xb + xi);
+        const int d = db + di;
+        if (slot < q.cap) {
+            q.entries[slot] = exact_entry(pix, d, sides);
+            if (q.ekeys) {
+                uint32_t key = 0;
+#pragma unroll
+                for (int a = 0; a < RX; ++a)
+#pragma unroll
+                    for (int c2 = 0; c2 < RD; ++c2)
+                        if (a * RD + c2 == b) key = kk[a][c2];
+                q.ekeys[slot] = key;
+            }
+        }
+        if ((sides & EXACT_SIDE_L) && q.flagL) q.flagL[pix] = 1;
+        if ((sides & EXACT_SIDE_R) && q.flagR) q.flagR[pix - (uint32_t)d] = 1;
+        ++slot;
     }
 }
 
@@ -279,17 +366,18 @@ template <bool RIGHT>
 __device__ __forceinline__ void asw_exact_merge(const AswExactQueue &q, bool have, u64 mine, u64 old, uint32_t rowpix, int xcol)
 {
     bool want = false;
-    uint32_t pix = 0;
+    uint32_t pix = 0, key = 0;
     int d = 0;
     if (have && old != KEY_NONE) {
         const u64 lo = mine < old ? mine : old, hi = mine < old ? old : mine;
-        if (exact_near_local((uint32_t)(hi >> 32), (uint32_t)(lo >> 32), q.tol, q.sat_abs)) {
+        if ((uint32_t)(hi >> 32) < q.deep && exact_near_local((uint32_t)(hi >> 32), (uint32_t)(lo >> 32), q.tol, q.sat_abs)) {
             want = true;
+            key = (uint32_t)(hi >> 32);
             if (RIGHT) { const int xl = (int)(uint32_t)hi; pix = rowpix + (uint32_t)xl; d = xl - xcol; }
             else { pix = rowpix + (uint32_t)xcol; d = (int)(uint32_t)hi; }
         }
     }
-    asw_exact_push_wave(q, want, pix, d, RIGHT ? EXACT_SIDE_R : EXACT_SIDE_L);
+    asw_exact_push_wave(q, want, pix, d, RIGHT ? EXACT_SIDE_R : EXACT_SIDE_L, key);
 }
 
 // wL / wR rows are stored with their even and odd 16-byte blocks in two halves ("parity split"):
@@ -622,6 +710,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     // ---- weighted average (_passive.cpp:88) and the two WTA reductions
     int tidf = threadIdx.x;
     asm volatile("" : "+v"(tidf));
+    uint32_t kk[RX][ASW_RD];                      // cost images of the register tile (exact mode re-reads them after the barrier)
     if (tidf < g.XG * g.DG) {
         const int xg = tidf % g.XG, dg = tidf / g.XG;
         u64 diag[RX + ASW_RD - 1];
@@ -635,9 +724,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
             for (int di = 0; di < ASW_RD; ++di) {
                 const int d = dlo + ASW_RD * dg + di;
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
+                kk[xi][di] = 0xffffffffu;
                 if (valid) {
                     float c;
                     const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
+                    kk[xi][di] = (uint32_t)(hi >> 32);
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
@@ -659,8 +750,8 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     if (xq) {
         const bool live = tidf < g.XG * g.DG;
         const int xg = live ? tidf % g.XG : 0, dg = live ? tidf / g.XG : 0;
-        asw_exact_select<RX, ASW_RD>(A.xq, live, accN, accS, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
-                                     x0 + RX * xg, dlo + ASW_RD * dg, W, A.maxD, (uint32_t)orow);
+        asw_exact_select<RX, ASW_RD>(A.xq, live, kk, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
+                                     x0 + RX * xg, dlo + ASW_RD * dg, (uint32_t)orow);
     }
     if (A.disp) {
         for (int k = tid; k < Tx; k += nthr) {

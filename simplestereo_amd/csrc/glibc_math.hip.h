@@ -50,8 +50,10 @@ GM_TABLE uint64_t gm_exp_tab[256] = GLIBC_EXP_TAB_INIT;              // T[k] (re
 GM_TABLE uint64_t gm_exp2f_tab[32] = GLIBC_EXP2F_TAB_INIT;           // 2^(k/32) - (k << 52) / 32
 GM_TABLE double gm_powf_log2_tab[32] = GLIBC_POWF_LOG2_TAB_INIT;     // 1 / c_i, log2(c_i)
 
-// glibc exp(double), FMA build (e_exp.c with the polynomial steps fused; specialcase() unfused, as the library's is)
-GM_FN double glibc_exp(double x)
+// glibc exp(double), FMA build (e_exp.c with the polynomial steps fused; specialcase() unfused, as the library's is).
+// tab: the 256-entry table in whatever memory the caller staged it (the fp64 tie-break pass keeps it in LDS: per-lane indices into
+// constant memory are two dependent global loads per call).
+GM_FN double glibc_exp_t(double x, const uint64_t *tab)
 {
     GM_CONTRACT_OFF
     uint32_t abstop = (uint32_t)(gm_asu64(x) >> 52) & 0x7ffu;
@@ -70,8 +72,8 @@ GM_FN double glibc_exp(double x)
     kd -= GLIBC_EXP_SHIFT;
     const double r = fma(kd, GLIBC_EXP_NEGLN2LON, fma(kd, GLIBC_EXP_NEGLN2HIN, x));
     const uint64_t idx = 2 * (ki % 128), top = ki << (52 - 7);
-    const double tail = gm_asf64(gm_exp_tab[idx]);
-    uint64_t sbits = gm_exp_tab[idx + 1] + top;
+    const double tail = gm_asf64(tab[idx]);
+    uint64_t sbits = tab[idx + 1] + top;
     const double r2 = r * r;
     const double a = fma(r, GLIBC_EXP_C3, GLIBC_EXP_C2), b = fma(r, GLIBC_EXP_C5, GLIBC_EXP_C4);
     const double tmp = fma(r2 * r2, b, fma(r2, a, tail + r));
@@ -96,6 +98,8 @@ GM_FN double glibc_exp(double x)
     const double scale = gm_asf64(sbits);
     return fma(scale, tmp, scale);
 }
+
+GM_FN double glibc_exp(double x) { return glibc_exp_t(x, gm_exp_tab); }
 
 // glibc powf(x, y) for normal positive x and finite y whose result neither overflows nor underflows (e_powf.c: log2_inline,
 // exp2_inline, sign_bias 0) -- the Lab conversion calls it with x in (0.008856, ~1.1] and y = (float)(1 / 3.0).

@@ -247,8 +247,8 @@ struct Ctx {
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
     DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol, altdisp;
-    DevBuf xlabL, xlabR, xflags, xqueue, xcost, xslots, xctr;      // fp64 tie-break pass (asw_exact_kernels.hip.h)
-    unsigned int xcap = 0;              // queue capacity of the last exact call
+    DevBuf xlabL, xlabR, xflags, xqueue, xcost, xslots, xctr, xraw;      // fp64 tie-break pass (asw_exact_kernels.hip.h)
+    unsigned int xcap = 0, xrawcap = 0; // queue capacities of the last exact call
     TableCache proxTabs{8}, gswTabs{4}, proxTabs64{8};
     std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
     hipEvent_t scratch_free = nullptr;  // recorded after the last kernel that uses the scratch buffers
@@ -913,23 +913,31 @@ int get_prox64(Ctx &c, int win, double gammaP, hipStream_t s, const double **out
 
 // fp64 tie-break pass (asw_exact_kernels.hip.h), part 1 -- BEFORE the aggregation: queue, pixel flags and counters of this call;
 // fills the AswExactQueue the aggregation kernels append their near-ties to (round 6: no cost-image volume).
-int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, bool consistent, hipStream_t s, AswExactQueue &q)
+int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, bool consistent, bool direct, hipStream_t s,
+                      AswExactQueue &q, AswExactQueue &raw, AswExactQueue &kernel_q)
 {
     const size_t nout = (size_t)rows * W;
     if (nout >= ((size_t)1 << 32)) return fail(SSAMD_ELIMIT, "exact mode: more than 2^32 output pixels per call");
     // queue: room for a few candidates of every pixel, bounded (a frame of saturated noise can flag every candidate of every
     // pixel; an overflow leaves the fp32 map and is reported: `exact_overflow`); frames of up to 4M candidates in all get room
-    // for every one of them -- a flat test image cannot overflow
-    size_t cap = std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(nout * (size_t)nD + nout, (size_t)1 << 22)), (size_t)1 << 25);
+    // for every one of them on both sides -- a flat test image cannot overflow
+    // (a candidate can be queued once per side -- by a select and by a merge, or by the left and the right escalation)
+    const size_t all_cands = 2 * (nout * (size_t)nD + nout);
+    size_t cap = std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(all_cands, (size_t)1 << 23)), (size_t)1 << 25);
     if (tune().exact_cap) cap = (size_t)tune().exact_cap;
+    // raw queue of merging calls (12 B per entry): what workgroups select against their tile-local winners
+    size_t rawcap = direct ? 0 : std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(all_cands, (size_t)1 << 23)), (size_t)1 << 26);
+    if (!direct && tune().exact_cap) rawcap = std::max<size_t>(rawcap, cap);
     int rc;
     // [64 B counters][flagL nout][flagR nout]: one buffer, one memset
     if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(64 + 2 * nout)) ||
-        (rc = c.xslots.reserve(nout * 24)))
+        (rc = c.xslots.reserve(nout * 24)) || (rawcap && (rc = c.xraw.reserve(rawcap * 12))))
         return rc;
     c.xcap = (unsigned int)cap;
+    c.xrawcap = (unsigned int)rawcap;
     HIP_TRY(hipMemsetAsync(c.xflags.ptr, 0, 64 + (consistent ? 2 : 1) * nout, s));
     q.entries = (u64 *)c.xqueue.ptr;
+    q.ekeys = nullptr;
     q.counter = (unsigned int *)c.xflags.ptr;
     q.flagL = (unsigned char *)c.xflags.ptr + 64;
     q.flagR = consistent ? q.flagL + nout : nullptr;
@@ -944,12 +952,25 @@ int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, b
     // denominator each, u = 2^-53, i.e. 2 (n + 3) u 40 absolute near the cap; two candidates can swap places when they are
     // closer than twice that (x 1.5 margin)
     q.sat_abs = (float)(1.5 * 2.0 * 2.0 * ((double)win * win + 3.0) * 1.1102230246251565e-16 * 40.0);
+    q.deep = 0xffffffffu;
+    raw = AswExactQueue{};
+    if (!direct) {
+        raw = q;
+        union { float f; uint32_t u; } sa; sa.f = q.sat_abs;
+        raw.deep = 0xC0000000u - sa.u;                                   // images with 40 - cost <= sat_abs stay out of the raw queue
+        raw.entries = (u64 *)c.xraw.ptr;
+        raw.ekeys = (uint32_t *)((u64 *)c.xraw.ptr + rawcap);
+        raw.counter = q.counter + 4;
+        raw.flagL = raw.flagR = nullptr;
+        raw.cap = (unsigned int)rawcap;
+    }
+    kernel_q = direct ? q : raw;
     return SSAMD_OK;
 }
 
 // ... part 2 -- AFTER the aggregation: the queue holds the near-ties of every winner, c.keyL / c.keyR (or the map itself when the
 // aggregation wrote it: `direct`) the fp32 winners.  Rewrites the winners of pixels whose near-ties fp64 decides differently.
-int asw_exact_pass(Ctx &c, const AswExactQueue &q, int H, int W, int row0, int rows, int win, int maxD, int minD, double gammaC, double gammaP,
+int asw_exact_pass(Ctx &c, const AswExactQueue &q, const AswExactQueue &raw, int H, int W, int row0, int rows, int win, int maxD, int minD, double gammaC, double gammaP,
                    bool consistent, bool direct, int16_t *d_disp, hipStream_t s)
 {
     const int p = win / 2;
@@ -965,6 +986,7 @@ int asw_exact_pass(Ctx &c, const AswExactQueue &q, int H, int W, int row0, int r
     x.keyL = direct ? nullptr : (u64 *)c.keyL.ptr; x.keyR = consistent ? (u64 *)c.keyR.ptr : nullptr;
     x.disp = d_disp;
     x.q = q;
+    x.raw = raw;
     x.ecost = (double *)c.xcost.ptr;
     x.costL = (u64 *)c.xslots.ptr; x.costR = x.costL + nout;
     x.idxL = (uint32_t *)(x.costR + nout); x.idxR = x.idxL + nout;
@@ -979,8 +1001,12 @@ int asw_exact_pass(Ctx &c, const AswExactQueue &q, int H, int W, int row0, int r
                            (double *)c.xlabL.ptr + 3 * (size_t)r0 * W, (double *)c.xlabR.ptr + 3 * (size_t)r0 * W, np2);
     }
     const int pb = (int)std::min<long long>(((long long)nout + 255) / 256, 256 * 8);
+    if (raw.entries) {
+        hipLaunchKernelGGL(asw_exact_filter_kernel, dim3(256 * 8), dim3(256), 0, s, x);
+        hipLaunchKernelGGL(asw_exact_escalate_kernel, dim3(pb), dim3(256), 0, s, x);
+    }
     hipLaunchKernelGGL(asw_exact_winners_kernel, dim3(pb), dim3(256), 0, s, x);
-    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 4), dim3(64 * EXACT_WAVES), 0, s, x);
+    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 6), dim3(64 * EXACT_WAVES), 0, s, x);
     hipLaunchKernelGGL(asw_exact_resolve_kernel, dim3(256 * 4), dim3(256), 0, s, x);
     hipLaunchKernelGGL(asw_exact_patch_kernel, dim3(pb), dim3(256), 0, s, x);
     HIP_TRY(hipGetLastError());
@@ -1041,6 +1067,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     // One disparity chunk and no right-referenced pass: each pixel is decided by exactly one workgroup, which then
     // writes the disparity itself -- no key buffer, atomics or decode kernel (34 instead of 48+ bytes of HBM per pixel).
     AswArgs a{};
+    AswExactQueue xq_final{}, xq_raw{};                               // exact mode: the final near-tie queue and, for merging calls, the raw one
     const int grows = alternate ? (rows + 1) / 2 : rows - skip;       // workgroup rows: every row (of both ranges), or the even ones
     if (nD >= 1 && (rc = asw_choose_geometry(a.g, W, grows, win, nD))) return rc;
     // Autotuning (ssamd_autotune): the first call for a problem shape times the best geometry of every class of
@@ -1413,7 +1440,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                     if (need_keys) HIP_TRY(hipMemsetAsync(c.keyL.ptr, 0xFF, nout * 8, s));
                     if (consistent) HIP_TRY(hipMemsetAsync(c.keyR.ptr, 0xFF, nout * 8, s));
                 }
-                if ((rc = asw_exact_prepare(c, W, rows, win, nD, gammaC, consistent != 0, s, a.xq))) return rc;
+                if ((rc = asw_exact_prepare(c, W, rows, win, nD, gammaC, consistent != 0, is_direct(final_geom), s, xq_final, xq_raw, a.xq))) return rc;
             }
             Timed t(c, s, SSAMD_K_ASW_AGG);
             if ((rc = launch(final_geom))) return rc;
@@ -1421,7 +1448,7 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
     }
     const bool direct = is_direct(a.g);
     if (exact && nD >= 1 &&
-        (rc = asw_exact_pass(c, a.xq, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent != 0, direct, d_disp, s)))
+        (rc = asw_exact_pass(c, xq_final, xq_raw, H, W, row0, rows, win, maxD, minD, gammaC, gammaP, consistent != 0, direct, d_disp, s)))
         return rc;
     if (!direct && skip > 0) {
         // decode / left-right check of the two bands only (row-local: _passive.cpp:251-285); the rows between keep what the
@@ -1979,14 +2006,15 @@ int ssamd_counter(int device, const char *name, long long *value)
     else if (n == "evol_bytes") *value = (long long)c->evol.cap;
     else if (n == "tail_splits") *value = c->tail_splits;
     else if (n == "exact_calls") *value = c->exact_calls;
-    else if (n == "exact_entries" || n == "exact_flagged_left" || n == "exact_flagged_right" || n == "exact_overflow") {
+    else if (n == "exact_entries" || n == "exact_flagged_left" || n == "exact_flagged_right" || n == "exact_overflow" || n == "exact_raw_entries") {
         // of the LAST exact call on this device: candidates re-evaluated in fp64, pixels with near-ties, whether the queue overflowed
-        unsigned int ctr[3] = {0, 0, 0};
+        unsigned int ctr[5] = {0, 0, 0, 0, 0};
         if (c->xflags.ptr && c->exact_calls > 0) {       // (the counters are the first 64 bytes of the flag buffer: one memset per call)
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipMemcpy(ctr, c->xflags.ptr, sizeof(ctr), hipMemcpyDeviceToHost));
         }
-        *value = n == "exact_entries" ? ctr[0] : n == "exact_flagged_left" ? ctr[1] : n == "exact_flagged_right" ? ctr[2] : (ctr[0] > c->xcap ? 1 : 0);
+        *value = n == "exact_entries" ? ctr[0] : n == "exact_flagged_left" ? ctr[1] : n == "exact_flagged_right" ? ctr[2] :
+                 n == "exact_raw_entries" ? ctr[4] : ((ctr[0] > c->xcap || (c->xrawcap && ctr[4] > c->xrawcap)) ? 1 : 0);
     }
     else return fail(SSAMD_EINVAL, "unknown counter %s", name);
     return SSAMD_OK;
@@ -2409,6 +2437,30 @@ __global__ void debug_libm_kernel(int which, int n, const void *in, void *out)
     else reinterpret_cast<double *>(out)[i] = reinterpret_cast<const double *>(in)[i] / 0.7 + reinterpret_cast<const double *>(in)[i] / 5.0;
 }
 }  // namespace
+
+// Verification / diagnosis: the queues of the LAST exact call on the current device.  which = 0: the final queue (entries
+// re-evaluated in fp64), 1: the raw queue of a merging call with its cost images.  Copies up to max_n entries; *n = entries appended.
+int ssamd_debug_exact_queue(int which, long long max_n, unsigned long long *entries, unsigned int *keys, long long *n)
+{
+    if (!n || max_n < 0 || (max_n > 0 && !entries)) return fail(SSAMD_EINVAL, "bad argument");
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    *n = 0;
+    if (!c->xflags.ptr || c->exact_calls == 0) return SSAMD_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned int ctr[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(ctr, c->xflags.ptr, sizeof(ctr), hipMemcpyDeviceToHost));
+    const unsigned int cnt = which ? ctr[4] : ctr[0], cap = which ? c->xrawcap : c->xcap;
+    *n = cnt;
+    const size_t m = (size_t)std::min<long long>(std::min<unsigned int>(cnt, cap), max_n);
+    if (m == 0) return SSAMD_OK;
+    const void *src = which ? c->xraw.ptr : c->xqueue.ptr;
+    if (!src) return SSAMD_OK;
+    HIP_TRY(hipMemcpy(entries, src, m * 8, hipMemcpyDeviceToHost));
+    if (which && keys) HIP_TRY(hipMemcpy(keys, (const char *)src + (size_t)c->xrawcap * 8, m * 4, hipMemcpyDeviceToHost));
+    return SSAMD_OK;
+}
 
 int ssamd_debug_libm(int which, int n, const void *in, void *out)
 {

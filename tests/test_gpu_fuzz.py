@@ -72,6 +72,12 @@ def test_asw_fuzz_vs_oracle(case, ss):
     assert bad <= max(1, 0.005 * H * W), (case, bad)
     assert ties <= max(2, 0.005 * H * W), (case, ties)
     assert bad + ties <= max(2, 0.005 * H * W), (case, bad, ties)      # north_star's bar with NO exclusion
+    # round 6: the default path re-decides near-ties in fp64 in the reference's arithmetic -- the map is the oracle's, bit for bit;
+    # the fp32 argmin alone (exact=False) is held to the bars above
+    assert np.array_equal(d, ref), (case, int(np.count_nonzero(d != ref)))
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(a, b)
+    bad32 = int(np.count_nonzero(np.abs(d32.astype(np.int32) - ref) > 1))
+    assert bad32 <= max(2, 0.005 * H * W), (case, bad32)
 
 
 def _gpu_argmins(a, b, p):
@@ -100,9 +106,11 @@ def test_asw_consistent_fuzz_vs_oracle(case, ss):
     H, W, win, minD, maxD, _, seed = case
     a, b = _shifted_pair(H, W, minD, maxD, seed)
     p = dict(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=float(3 + seed % 9), gammaP=float(5 + seed % 20))
-    d = ss.passive.StereoASW(consistent=True, **p).compute(a, b)
+    # (exact=False: this test takes the fp32 path apart -- ssamd_asw_argmins dumps the fp32 argmins; the default path, whose near-ties
+    #  are re-decided in fp64, is held to the oracle's map itself in tests/test_gpu_exact.py)
+    d = ss.passive.StereoASW(consistent=True, exact=False, **p).compute(a, b)
     gl, gr = _gpu_argmins(a, b, p)
-    assert np.array_equal(gl, ss.passive.StereoASW(**p).compute(a, b))             # the left argmin IS the plain map
+    assert np.array_equal(gl, ss.passive.StereoASW(exact=False, **p).compute(a, b))             # the left argmin IS the plain map
     assert np.array_equal(d, _lr_check_fill_literal(gl, gr)), case                   # (1)
     ref = oracle.asw(a, b, consistent=True, **p)
     _, cref = oracle.asw(a, b, return_costs=True, **p)
