@@ -875,7 +875,9 @@ def main():
                 "interior_ms": phases.get("interior_ms"), "border_ms": phases.get("border_ms"),
                 "halo_exchange_exposed_ms": phases.get("exchange_exposed_ms"),
                 "aggregation_launches_per_step": launches[_native.K_ASW_AGG] / float(max(1, args.steps)),
-                "gather_ms": phases.get("gather_ms"), "messages_sent": len(strip_ctx.sends), "messages_received": len(strip_ctx.recvs)}
+                "gather_ms": phases.get("gather_ms"), "messages_sent": len(strip_ctx.sends), "messages_received": len(strip_ctx.recvs),
+                # CPU time inside StripContext.step per step (no synchronisation): must stay well below the strip's kernel time
+                "host_step_ms": phases.get("host_step_ms")}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "flat_all_gather_into_tensor": bool(strip_ctx.flat_gather),
@@ -890,6 +892,14 @@ def main():
         ks = [r["kernel_ms"] for r in per_rank if r and r.get("kernel_ms")]
         if ks:
             rccl["kernel_ms_min"], rccl["kernel_ms_max"] = min(ks), max(ks)
+        hs = [r["host_step_ms"] for r in per_rank if r and r.get("host_step_ms") is not None]
+        if hs:
+            rccl["host_step_ms_max"] = max(hs)
+        ex = [r.get("halo_exchange_exposed_ms") for r in per_rank if r and r.get("overlapped")]
+        if ex and all(v is not None for v in ex):
+            # the halo exchange ran under the interior rows on every rank (what is left exposed is below 50 us)
+            rccl["exchange_hidden"] = bool(max(ex) < 0.05)
+            rccl["exchange_exposed_ms_max"] = max(ex)
     checksum = int(out.to(torch.int64).sum().item())
     bad1_dist = None
     if world > 1 and not args.no_bad1:

@@ -117,6 +117,15 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                      int gamma, float fMax, int iterations, int bins,
                      int16_t *d_disparity, void *stream);
 
+/* ssamd_gsw_device on two row ranges (same meaning as ssamd_asw_device_rows2; each band is matched by a call of its own:
+ * GSW's workgroups are small and a band is winSize/2 rows).  Reference anchor: row-local jobs and row-local left-right check,
+ * _passive.cpp:754-771, 661-696. */
+int ssamd_gsw_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width,
+                           int out_row0, int out_rows, int skip_row0, int skip_rows,
+                           int winSize, int maxDisparity, int minDisparity,
+                           int gamma, float fMax, int iterations, int bins,
+                           int16_t *d_disparity, void *stream);
+
 /* ---- ASW with the reference's fp64 argmin on near-ties ("exact" mode; what StereoASW runs by default since round 6) -----
  * The reference aggregates in double (_passive.cpp:23, 56-95); ssamd_asw* accumulate in fp32 and may pick the other one of
  * two candidates whose costs agree to ~1e-6 relative (a fraction of a percent of the pixels at worst).  These entry points

@@ -82,6 +82,8 @@ def lib():
     L.ssamd_asw_exact_multi.argtypes = [P, P, I, I, I, I, I, D, D, I, P, ctypes.POINTER(I), I]
     L.ssamd_asw_exact_device.restype = I
     L.ssamd_asw_exact_device.argtypes = [P, P, I, I, I, I, I, I, I, D, D, I, P, P]
+    L.ssamd_gsw_device_rows2.restype = I
+    L.ssamd_gsw_device_rows2.argtypes = [P, P, I, I, I, I, I, I, I, I, I, I, F, I, I, P, P]
     L.ssamd_asw_exact_device_rows2.restype = I
     L.ssamd_asw_exact_device_rows2.argtypes = [P, P, I, I, I, I, I, I, I, I, I, D, D, I, P, P]
     L.ssamd_asw_exact_rectified_device.restype = I

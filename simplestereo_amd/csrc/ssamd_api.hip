@@ -2347,6 +2347,35 @@ int ssamd_gsw_device(const uint8_t *d_img1, const uint8_t *d_img2, int height, i
                            gamma, fMax, iterations, d_disparity, (hipStream_t)stream);
 }
 
+// ssamd_gsw_device on TWO row ranges (round 6: the border bands of a row strip whose interior rows ran while the halo was in flight,
+// strips.py).  GSW workgroups are small (two 8-wave groups per CU, strips of 2-8 rows) and a band is winSize/2 = 5 rows at the class
+// default: each band is an ordinary call on its rows -- pack, both passes, left-right check -- written at its place in d_disparity.
+int ssamd_gsw_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int height, int width, int out_row0, int out_rows,
+                           int skip_row0, int skip_rows, int winSize, int maxDisparity, int minDisparity, int gamma, float fMax,
+                           int iterations, int bins, int16_t *d_disparity, void *stream)
+{
+    (void)bins;
+    if (!d_img1 || !d_img2 || !d_disparity) return fail(SSAMD_EINVAL, "NULL buffer");
+    if (skip_rows < 0 || (skip_rows > 0 && (skip_row0 < out_row0 || skip_row0 + skip_rows > out_row0 + out_rows)))
+        return fail(SSAMD_EINVAL, "the skipped rows [%d,%d) must lie inside the output rows [%d,%d)", skip_row0, skip_row0 + skip_rows,
+                    out_row0, out_row0 + out_rows);
+    CtxLock c;
+    int rc = get_ctx(-1, c);
+    if (rc) return rc;
+    if (skip_rows == 0)
+        return gsw_device_impl(*c, d_img1, d_img2, height, width, out_row0, out_rows, winSize, maxDisparity, minDisparity,
+                               gamma, fMax, iterations, d_disparity, (hipStream_t)stream);
+    if ((rc = check_common(height, width, winSize, minDisparity, maxDisparity, out_row0, out_rows))) return rc;
+    const int top = skip_row0 - out_row0, bot0 = skip_row0 + skip_rows, bot = out_row0 + out_rows - bot0;
+    if (top > 0 && (rc = gsw_device_impl(*c, d_img1, d_img2, height, width, out_row0, top, winSize, maxDisparity, minDisparity,
+                                         gamma, fMax, iterations, d_disparity, (hipStream_t)stream)))
+        return rc;
+    if (bot > 0 && (rc = gsw_device_impl(*c, d_img1, d_img2, height, width, bot0, bot, winSize, maxDisparity, minDisparity,
+                                         gamma, fMax, iterations, d_disparity + (size_t)(bot0 - out_row0) * width, (hipStream_t)stream)))
+        return rc;
+    return SSAMD_OK;
+}
+
 int ssamd_gsw_rectified_device(const uint8_t *d_raw1, const uint8_t *d_raw2, int src_height, int src_width,
                                const float *d_mapx1, const float *d_mapy1, const float *d_mapx2, const float *d_mapy2,
                                int height, int width, int interpolation, int winSize, int maxDisparity, int minDisparity,

@@ -472,7 +472,9 @@ class StereoGSW():
                 _raise_native(e)
         return out
 
-    def _compute_device(self, t1, t2, out_row0=0, out_rows=None):
+    def _compute_device(self, t1, t2, out_row0=0, out_rows=None, out=None, skip=None):
+        """see StereoASW._compute_device: ``out`` = a contiguous int16 [out_rows, W] tensor to write into, ``skip = (row, n)`` =
+        rows left untouched between two bands (``ssamd_gsw_device_rows2``; the overlapped strip step of strips.py)"""
         import torch
         lib = _native.lib()
         win, maxd, mind, gamma, fmax, it, bins = self._params()
@@ -481,10 +483,17 @@ class StereoGSW():
             raise ValueError("winSize must be a positive odd number!")
         H, W = int(a.shape[0]), int(a.shape[1])
         rows = H - out_row0 if out_rows is None else int(out_rows)
-        out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        if out is None:
+            out = torch.empty((rows, W), dtype=torch.int16, device=a.device)
+        elif out.dtype != torch.int16 or tuple(out.shape) != (rows, W) or not out.is_contiguous() or out.device != a.device:
+            raise ValueError("out must be a contiguous int16 [out_rows, W] tensor on the images' device")
         with torch.cuda.device(a.device):
             stream = torch.cuda.current_stream(a.device).cuda_stream
             try:
+                if skip is not None and skip[1] > 0:
+                    _native.check(lib.ssamd_gsw_device_rows2(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, int(skip[0]), int(skip[1]),
+                                                             win, maxd, mind, gamma, fmax, it, bins, out.data_ptr(), ctypes.c_void_p(stream)))
+                    return out
                 _native.check(lib.ssamd_gsw_device(a.data_ptr(), b.data_ptr(), H, W, int(out_row0), rows, win,
                                                    maxd, mind, gamma, fmax, it, bins, out.data_ptr(),
                                                    ctypes.c_void_p(stream)))

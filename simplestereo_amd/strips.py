@@ -163,11 +163,17 @@ class StripContext:
     through host buffers; the kernels still run on `device`.
     """
 
-    def __init__(self, matcher, height, width, rank, world_size, device, group=None, overlap=True):
+    def __init__(self, matcher, height, width, rank, world_size, device, group=None, overlap=True, loopback=False):
+        """loopback=True (TIMING HARNESS, tools/strip_host_cost.py): `rank` / `world_size` are VIRTUAL -- the strip, halo and message
+        sizes of that rank of that world -- while every message goes to this very process (isend / irecv to self in one batched
+        group, the p2p_self_probe pattern) and nothing is gathered: the real step of an 8-GPU run (copies, RCCL group on the side
+        stream, interior launch, border launch) with its real sizes on a box with ONE GPU.  The halo rows it receives are its own
+        border rows, so the map is NOT the whole frame's: for timing only."""
         import torch
         import torch.distributed as dist
         self.matcher, self.H, self.W = matcher, int(height), int(width)
         self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.loopback = bool(loopback)
         self.device = torch.device(device)
         backend = dist.get_backend(group) if dist.is_initialized() else None
         self.flat_gather = backend == "nccl"                  # gloo has no all_gather_into_tensor
@@ -190,13 +196,14 @@ class StripContext:
         # the message list of a step never changes (fixed buffers, fixed peers): built once
         self._ops = []
         if self.world > 1 and dist.is_initialized():
+            me = dist.get_rank(self.group) if self.loopback else None
             for (dst, lo, hi), (bl, br) in zip(self.sends, self.send_bufs):
-                self._ops.append(dist.P2POp(dist.isend, bl, dst, group=self.group))
-                self._ops.append(dist.P2POp(dist.isend, br, dst, group=self.group))
+                self._ops.append(dist.P2POp(dist.isend, bl, me if self.loopback else dst, group=self.group))
+                self._ops.append(dist.P2POp(dist.isend, br, me if self.loopback else dst, group=self.group))
             for k, (src, lo, hi) in enumerate(self.recvs):
                 tl, tr = self.recv_bufs[k] if self.staged else (self.subL[lo:hi], self.subR[lo:hi])
-                self._ops.append(dist.P2POp(dist.irecv, tl, src, group=self.group))
-                self._ops.append(dist.P2POp(dist.irecv, tr, src, group=self.group))
+                self._ops.append(dist.P2POp(dist.irecv, tl, me if self.loopback else src, group=self.group))
+                self._ops.append(dist.P2POp(dist.irecv, tr, me if self.loopback else src, group=self.group))
         self.rows_max = -(-self.H // self.world)
         self.padded = torch.zeros((self.rows_max, self.W), dtype=torch.int16, device=cdev)
         self.gathered = torch.empty((self.world, self.rows_max, self.W), dtype=torch.int16, device=cdev)
@@ -220,11 +227,16 @@ class StripContext:
         self.bot = n - self.top - self.interior
         if mode == "0":
             overlap = False
-        self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ == "StereoASW" and
+        # (round 6: StereoGSW too -- ssamd_gsw_device_rows2; exact mode rides along -- ssamd_asw_exact_device_rows2)
+        self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ in ("StereoASW", "StereoGSW") and
                             not getattr(matcher, "alternate", False) and
                             self.world > 1 and self._ops and self.interior > 0 and self.top + self.bot > 0)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self.strip_out = torch.empty((n, self.W), dtype=torch.int16, device=self.device) if self.overlap else None
+        # the two cross-stream events of a step are made ONCE (a torch.cuda.Event() per step was two allocations on the host path)
+        self._ev_copied = torch.cuda.Event() if self.overlap else None
+        self._ev_arrived = torch.cuda.Event() if self.overlap else None
+        self.host_s, self.host_steps = 0.0, 0          # host time spent inside step() (no synchronisation): read_timing()["host_step_ms"]
         self._timing = None           # list of per-step event tuples while enable_timing() is on (GPU devices only)
 
     def _whole_rounds(self, matcher, interior):
@@ -272,6 +284,10 @@ class StripContext:
             out["exchange_ms"] = sum(t["e0"].elapsed_time(t["e1"]) for t in self._timing) / n
         out["kernels_ms"] = sum(t["e1"].elapsed_time(t["e2"]) for t in self._timing) / n
         out["gather_ms"] = sum(t["e2"].elapsed_time(t["e3"]) for t in self._timing) / n
+        # host side of a step: time the CPU spends inside step() enqueueing it (copies, event records, the RCCL group, two matcher
+        # calls, the gather) -- must stay well below the strip's kernel time or the GPU waits for its host (a 135-row strip of an
+        # 8-GPU config-3 run is ~5 ms); measured with the timing events on, i.e. an upper bound
+        out["host_step_ms"] = sum(t["host_s"] for t in self._timing) / n * 1e3
         return out
 
     def _mark(self, stream=None):
@@ -294,7 +310,12 @@ class StripContext:
                 self.subR[lo:hi].copy_(tr)
 
     def step(self, own_left, own_right, gather=True):
+        """One frame.  NOTE (aliasing): with the overlapped step the strip is written into the context's persistent buffer
+        `strip_out` -- with gather=False the caller gets THAT buffer, which the next step() overwrites asynchronously on the
+        stream; clone it to keep it.  With gather=True the result is the context's gather buffer, likewise reused."""
+        import time
         import torch
+        host0 = time.perf_counter()
         timing = self._timing is not None
         t = {"e0": self._mark()} if timing else None
         o0, o1 = self.r0 - self.h0, self.r1 - self.h0
@@ -302,7 +323,7 @@ class StripContext:
         self.subR[o0:o1].copy_(own_right)
         if self.overlap:
             main = torch.cuda.current_stream(self.device)
-            copied = torch.cuda.Event()
+            copied, arrived = self._ev_copied, self._ev_arrived
             copied.record(main)
             if timing:
                 t["e1"] = self._mark()
@@ -319,7 +340,6 @@ class StripContext:
                 self._exchange(own_left, own_right)
                 if timing:
                     t["x1"] = self._mark(self.side)
-                arrived = torch.cuda.Event()
                 arrived.record(self.side)
             main.wait_event(arrived)
             # ... then the border bands, one launch
@@ -333,9 +353,13 @@ class StripContext:
             strip = _match_rows(self.matcher, self.subL, self.subR, o0, self.r1 - self.r0, self.h0 & 1)
         if timing:
             t["e2"] = self._mark()
-        out = self._gather(strip) if gather else strip
+        out = self._gather(strip) if gather and not self.loopback else strip
+        dt = time.perf_counter() - host0
+        self.host_s += dt
+        self.host_steps += 1
         if timing:
             t["e3"] = self._mark()
+            t["host_s"] = dt
             self._timing.append(t)
         return out
 

@@ -294,3 +294,33 @@ def test_exact_mode_mini_soak_against_the_oracle(ss):
         assert np.array_equal(d, ref), (H, W, p, int(np.count_nonzero(d != ref)))
         done += 1
     assert done >= 40
+
+
+@pytest.mark.parametrize("win,H,W,maxd,cons", [(61, 40, 180, 24, False), (101, 36, 160, 12, True), (151, 30, 200, 10, False), (255, 20, 300, 6, False)])
+def test_large_windows_against_the_oracle(win, H, W, maxd, cons, ss):
+    """the near-tie band was a fixed 128 key ulps whatever the window -- at winSize 35 the (N, S') sums have 1 225
+    fp32 terms, at the allowed 255 they have 65 025.  The band now grows with the window (ssamd_api.hip asw_exact_prepare); here
+    windows of 61 .. 255 on textured, quantised and mirrored content against the fp64 oracle: the maps are equal, and the fp32
+    argmin alone stays inside north_star's tolerance."""
+    from oracle import oracle
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    for variant in range(3):
+        L, R, _ = make_pair(H, W, max(8, maxd), 700 + win + variant)
+        if variant == 1:                                   # quantised colours + a mirrored right image: wide saturated regions
+            L = (L // 64 * 64).astype(np.uint8)
+            R = np.ascontiguousarray(R[:, ::-1])
+        if variant == 2:                                   # low contrast: many candidates at nearly equal, unsaturated costs
+            L = (L // 8 + 100).astype(np.uint8)
+            R = (R // 8 + 100).astype(np.uint8)
+        L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+        p = dict(winSize=win, maxDisparity=maxd, minDisparity=0, consistent=cons, gammaC=5.0, gammaP=17.5)
+        ref = oracle.asw(L, R, **p)
+        d = ss.passive.StereoASW(exact=True, **p).compute(L, R)
+        assert _native.counter("exact_overflow") == 0
+        n = int(np.count_nonzero(d != ref))
+        d32 = ss.passive.StereoASW(exact=False, **p).compute(L, R)
+        n32 = int(np.count_nonzero(d32 != ref))
+        print("win %d variant %d: exact %d, fp32 %d of %d pixels differ from the oracle; %d candidates re-evaluated" %
+              (win, variant, n, n32, d.size, _native.counter("exact_entries")))
+        assert n == 0, (win, variant, n, n32)

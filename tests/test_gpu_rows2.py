@@ -97,3 +97,33 @@ def test_lab_records_and_tad_volume_in_one_launch_equal_two(H, W, params):
     assert torch.equal(sub_plain, fused[5:H - 6])
     # host arrays go through the same path
     assert np.array_equal(m.compute(L, R), fused.cpu().numpy())
+
+
+@pytest.mark.parametrize("H,W,params", [
+    (60, 300, dict(winSize=11, maxDisparity=16)),                          # class default StereoGSW()
+    (48, 500, dict(winSize=11, maxDisparity=100, minDisparity=2)),         # two disparity chunks
+    (40, 200, dict(winSize=21, maxDisparity=40, gamma=7)),
+])
+def test_gsw_two_row_ranges_equal_one_launch(H, W, params):
+    """ssamd_gsw_device_rows2 (round 6: the overlapped strip step for StereoGSW): the two bands equal the rows of one launch over
+    the whole range -- GSW is bit-exact, so equal means equal to the reference's rows -- and the rows in between stay untouched"""
+    import torch
+    import simplestereo_amd as ss
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(H, W, params["maxDisparity"], 17)
+    tL, tR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = ss.passive.StereoGSW(**params)
+    row0, rows = 2, H - 5
+    want = m._compute_device(tL, tR, out_row0=row0, out_rows=rows)
+    for skip0, nskip in ((row0 + 6, rows - 13), (row0, 9), (row0 + rows - 4, 4), (row0 + 3, 0), (row0, rows)):
+        out = torch.full((rows, W), -7, dtype=torch.int16, device="cuda")
+        got = m._compute_device(tL, tR, out_row0=row0, out_rows=rows, out=out, skip=(skip0, nskip))
+        assert got.data_ptr() == out.data_ptr()
+        a, b = skip0 - row0, skip0 - row0 + nskip
+        if nskip == 0:
+            assert torch.equal(out, want)
+            continue
+        assert torch.equal(out[:a], want[:a]) and torch.equal(out[b:], want[b:]), (params, skip0, nskip)
+        assert bool((out[a:b] == -7).all()), "rows between the two ranges were written"
+    with pytest.raises(ValueError):
+        m._compute_device(tL, tR, out_row0=row0, out_rows=rows, out=torch.empty((rows, W), dtype=torch.int16, device="cuda"), skip=(0, 3))

@@ -58,6 +58,10 @@ def _worker(rank, world, port, case, q):
     (2, ("asw", 61, 200, dict(winSize=21, maxDisparity=40, consistent=True, _overlap=True))),
     (3, ("asw", 50, 160, dict(winSize=35, maxDisparity=24, minDisparity=2))),      # strips thinner than the halo
     (2, ("gsw", 45, 150, dict(winSize=11, maxDisparity=30))),
+    # round 6: StereoGSW rides the overlapped step too (ssamd_gsw_device_rows2), and so does exact mode, which is what StereoASW() runs by
+    # default (ssamd_asw_exact_device_rows2): every ASW case below goes through the fp64 tie-break pass on each rank; one without it
+    (3, ("gsw", 70, 180, dict(winSize=11, maxDisparity=40, _overlap=True))),
+    (2, ("asw", 90, 200, dict(winSize=15, maxDisparity=40, exact=False, _overlap=True))),
     # round 5, the overlapped step: interior rows matched while the halo is in flight, the border bands as one launch --
     # direct-write path (one disparity chunk, no right pass) and keyed path; a middle rank with two bands; the wave kernel
     (2, ("asw", 90, 200, dict(winSize=15, maxDisparity=40, _overlap=True))),
