@@ -801,6 +801,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL's point-to-point kernels of the halo exchange on high-priority streams: they have to get onto a GPU that the interior
+        # rows' aggregation kernel keeps full (one 12-wave workgroup per CU) -- at normal priority they may only be dispatched when
+        # that kernel has no workgroup left to place, i.e. at its end (measured with the loopback harness, tools/strip_host_cost.py)
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

@@ -59,10 +59,26 @@ int main(int argc, char **argv)
             if (gm_asu32(powf(a, 2.4)) != gm_asu32(glibc_powf_pos(a, 2.4))) ++bad_powf;
         }
     }
+    /* the proximity tables of the ASW path (reference _passive.cpp:360-364: exp(-sqrt(di^2 + dj^2) / gammaP)): since round 6 the
+       library builds them with the restated exp on the host side -- every argument of every window up to 255 x 255, several gammaP */
+    long n_prox = 0;
+    {
+        const double gps[] = {17.5, 3.0, 100.0, 0.5, 36.0};
+        for (unsigned g = 0; g < sizeof(gps) / sizeof(gps[0]); ++g)
+            for (int di = 0; di <= 127; ++di)
+                for (int dj = di; dj <= 127; ++dj, ++n_prox) {
+                    const double x = -sqrt((double)di * di + (double)dj * dj) / gps[g];
+                    if (gm_asu64(exp(x)) != gm_asu64(glibc_exp(x))) {
+                        if (bad_exp < 5) printf("exp(%a): libm %a restatement %a\n", x, exp(x), glibc_exp(x));
+                        ++bad_exp;
+                    }
+                }
+    }
     if (bad_exp || bad_powf) {
         printf("libm_check FAILED: exp %ld of %ld, powf %ld of %ld differ\n", bad_exp, n, bad_powf, n_powf);
         return 1;
     }
-    printf("libm_check ok: exp %ld arguments, powf(x, 1/3) all %ld floats of [0.008856, 1.3] bit-identical to this libm\n", n, n_powf);
+    printf("libm_check ok: exp %ld arguments + %ld proximity-table arguments, powf(x, 1/3) all %ld floats of [0.008856, 1.3], powf(x, 2.4) the 256 sRGB "
+           "arguments: bit-identical to this libm\n", n, n_prox, n_powf);
     return 0;
 }

@@ -27,13 +27,18 @@
 #include "glibc_tables.hip.h"
 
 #ifdef __HIPCC__
-#define GM_FN __device__ __forceinline__
+#include <string.h>
+// host AND device (round 6): the host side of libssamd builds its own tables -- the sRGB byte table powf(x, 2.4f), the proximity
+// weights exp(-dist / gammaP) -- with THESE functions instead of the host's libm, so that the exact mode's bit-identity with the
+// goldens does not depend on which libm the host process happens to run on (musl, an older glibc, the non-FMA ifunc variant)
+#define GM_FN __host__ __device__ __forceinline__
 #define GM_TABLE __device__ __constant__
+#define GM_HOST_TABLES 1
 #define GM_CONTRACT_OFF _Pragma("clang fp contract(off)")
-GM_FN uint64_t gm_asu64(double x) { return (uint64_t)__double_as_longlong(x); }
-GM_FN double gm_asf64(uint64_t u) { return __longlong_as_double((long long)u); }
-GM_FN uint32_t gm_asu32(float x) { return __float_as_uint(x); }
-GM_FN float gm_asf32(uint32_t u) { return __uint_as_float(u); }
+GM_FN uint64_t gm_asu64(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+GM_FN double gm_asf64(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+GM_FN uint32_t gm_asu32(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+GM_FN float gm_asf32(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 #else
 #include <math.h>
 #include <string.h>
@@ -49,6 +54,11 @@ GM_FN float gm_asf32(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 GM_TABLE uint64_t gm_exp_tab[256] = GLIBC_EXP_TAB_INIT;              // T[k] (relative tail), H[k] - (k << 52) / 128
 GM_TABLE uint64_t gm_exp2f_tab[32] = GLIBC_EXP2F_TAB_INIT;           // 2^(k/32) - (k << 52) / 32
 GM_TABLE double gm_powf_log2_tab[32] = GLIBC_POWF_LOG2_TAB_INIT;     // 1 / c_i, log2(c_i)
+#ifdef GM_HOST_TABLES                                                // the same data for host code of a HIP translation unit
+static const uint64_t gm_exp_tab_h[256] = GLIBC_EXP_TAB_INIT;
+static const uint64_t gm_exp2f_tab_h[32] = GLIBC_EXP2F_TAB_INIT;
+static const double gm_powf_log2_tab_h[32] = GLIBC_POWF_LOG2_TAB_INIT;
+#endif
 
 // glibc exp(double), FMA build (e_exp.c with the polynomial steps fused; specialcase() unfused, as the library's is).
 // tab: the 256-entry table in whatever memory the caller staged it (the fp64 tie-break pass keeps it in LDS: per-lane indices into
@@ -99,7 +109,14 @@ GM_FN double glibc_exp_t(double x, const uint64_t *tab)
     return fma(scale, tmp, scale);
 }
 
-GM_FN double glibc_exp(double x) { return glibc_exp_t(x, gm_exp_tab); }
+GM_FN double glibc_exp(double x)
+{
+#if defined(GM_HOST_TABLES) && !defined(__HIP_DEVICE_COMPILE__)
+    return glibc_exp_t(x, gm_exp_tab_h);
+#else
+    return glibc_exp_t(x, gm_exp_tab);
+#endif
+}
 
 // glibc powf(x, y) for normal positive x and finite y whose result neither overflows nor underflows (e_powf.c: log2_inline,
 // exp2_inline, sign_bias 0) -- the Lab conversion calls it with x in (0.008856, ~1.1] and y = (float)(1 / 3.0).
@@ -138,4 +155,11 @@ GM_FN float glibc_powf_pos_t(float x, float y, const double *log2tab, const uint
     return (float)(yv * s);
 }
 
-GM_FN float glibc_powf_pos(float x, float y) { return glibc_powf_pos_t(x, y, gm_powf_log2_tab, gm_exp2f_tab); }
+GM_FN float glibc_powf_pos(float x, float y)
+{
+#if defined(GM_HOST_TABLES) && !defined(__HIP_DEVICE_COMPILE__)
+    return glibc_powf_pos_t(x, y, gm_powf_log2_tab_h, gm_exp2f_tab_h);
+#else
+    return glibc_powf_pos_t(x, y, gm_powf_log2_tab, gm_exp2f_tab);
+#endif
+}

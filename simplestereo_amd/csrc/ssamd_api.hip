@@ -317,11 +317,13 @@ int get_ctx(int device, CtxLock &out)
         HIP_TRY(hipEventCreateWithFlags(&c.scratch_free, hipEventDisableTiming));
     }
     if (!c.lut_ready) {
-        // sRGB byte -> linear*100 in the reference's float arithmetic (colorconversion.hpp:19-37)
+        // sRGB byte -> linear*100 in the reference's float arithmetic (colorconversion.hpp:19-37); powf = glibc's algorithm restated
+        // (glibc_math.hip.h, host side), NOT the host's libm: the same 256 floats on any host (oracle/libm_check.c proves them equal
+        // to glibc's, tests/test_gpu_libm_independence.py runs the path with the process's exp / powf replaced by garbage)
         float lut[256];
         for (int v = 0; v < 256; ++v) {
             float x = v / 255.0;
-            if (x > 0.04045) x = powf((x + 0.055) / 1.055, 2.4);
+            if (x > 0.04045) x = glibc_powf_pos((float)((x + 0.055) / 1.055), (float)2.4);
             else x /= 12.92;
             x *= 100;
             lut[v] = x;
@@ -866,7 +868,7 @@ int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
 #if SSAMD_W_FOLD
             e.host[(size_t)i * win + j] = (float)(-std::sqrt(di * di + dj * dj) / gammaP * 1.4426950408889634);      // log2 of the weight
 #else
-            e.host[(size_t)i * win + j] = (float)std::exp(-std::sqrt(di * di + dj * dj) / gammaP);
+            e.host[(size_t)i * win + j] = (float)glibc_exp(-std::sqrt(di * di + dj * dj) / gammaP);      // (restated exp: see get_prox64)
 #endif
         }
     int rc = e.dev.reserve(e.host.size() * 4);
@@ -881,8 +883,9 @@ int get_prox(Ctx &c, int win, double gammaP, hipStream_t s, const float **out)
     return SSAMD_OK;
 }
 
-// The same table in fp64, by the HOST's libm -- the reference builds it with the same expression and the same library
-// (_passive.cpp:360-364: exp(-sqrt(pow(i-padding,2) + pow(j-padding,2))/gammaP)) -- for the fp64 tie-break pass.
+// The same table in fp64 for the tie-break pass -- the reference's expression (_passive.cpp:360-364:
+// exp(-sqrt(pow(i-padding,2) + pow(j-padding,2))/gammaP)) with glibc's exp restated on the host side (round 6: rounds 1-5 called the
+// host's libm here, which made the exact mode's bit-identity a property of the host).
 int get_prox64(Ctx &c, int win, double gammaP, hipStream_t s, const double **out)
 {
     if (TableEntry *e = c.proxTabs64.find(win, gammaP)) { *out = (const double *)e->dev.ptr; return SSAMD_OK; }
@@ -898,7 +901,13 @@ int get_prox64(Ctx &c, int win, double gammaP, hipStream_t s, const double **out
     e.host64.resize((size_t)win * win);
     for (int i = 0; i < win; ++i)
         for (int j = 0; j < win; ++j)
-            e.host64[(size_t)i * win + j] = std::exp(-std::sqrt(std::pow(i - p, 2) + std::pow(j - p, 2)) / gammaP);
+            {
+                // exp: glibc's algorithm restated (glibc_math.hip.h), not the host's libm -- bit-identical to glibc's on every argument
+                // oracle/libm_check.c tries, and the same on a host that runs another libm.  pow(int, 2) is exact, sqrt and the
+                // division are IEEE operations (one correctly rounded result on any conforming host)
+                const double di = i - p, dj = j - p;
+                e.host64[(size_t)i * win + j] = glibc_exp(-std::sqrt(di * di + dj * dj) / gammaP);
+            }
     int rc = e.dev.reserve(e.host64.size() * 8);
     if (rc) { c.proxTabs64.entries.pop_front(); return rc; }
     hipError_t he = hipMemcpyAsync(e.dev.ptr, e.host64.data(), e.host64.size() * 8, hipMemcpyHostToDevice, s);

@@ -228,7 +228,19 @@ class StripContext:
         if mode == "0":
             overlap = False
         # (round 6: StereoGSW too -- ssamd_gsw_device_rows2; exact mode rides along -- ssamd_asw_exact_device_rows2)
-        self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ in ("StereoASW", "StereoGSW") and
+        # StereoGSW has the two-range form as well, but its step is NOT overlapped by default: measured (tools/strip_host_cost.py,
+        # profiles/r06_strip_host_cost.txt) the 135-row strip of an 8-GPU config-4 run takes 1.28 ms sequentially and 1.48 ms
+        # overlapped -- the two 5-row border bands cost more launches than the 0.13 ms exchange they hide.  "force" turns it on.
+        # Likewise StereoASW(consistent=True): 5.73-5.96 ms overlapped against 5.51-5.58 ms sequentially for the same strip -- there the
+        # RCCL kernels only got onto the GPU when the interior rows' aggregation kernel had drained (TORCH_NCCL_HIGH_PRIORITY or not),
+        # so the exchange was exposed anyway and the second launch was pure cost.  Plain StereoASW: 5.40 vs 5.39 ms with the exchange
+        # fully hidden (exposed 0.0 ms) -- the default there, because on real xGMI peers the exchange can only be slower than the
+        # 0.12 ms of this loopback.  "force" / "all": overlap every matcher that has a two-range form.
+        everything = mode in ("force", "all", "gsw")
+        kinds = ("StereoASW", "StereoGSW") if everything else ("StereoASW",)
+        if type(matcher).__name__ == "StereoASW" and getattr(matcher, "consistent", False) and not everything:
+            overlap = False
+        self.overlap = bool(overlap and self.device.type == "cuda" and type(matcher).__name__ in kinds and
                             not getattr(matcher, "alternate", False) and
                             self.world > 1 and self._ops and self.interior > 0 and self.top + self.bot > 0)
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None

@@ -11,6 +11,7 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")      # (as bench.py sets it; TORCH_NCCL_HIGH_PRIORITY=0 in the environment for the A/B)
 import numpy as np, torch, torch.distributed as dist
 import simplestereo_amd as ss
 from simplestereo_amd import _native, strips
@@ -26,13 +27,15 @@ cases = [("asw c3 exact (default)", ss.passive.StereoASW(winSize=35, maxDisparit
          ("asw c3 fp32", ss.passive.StereoASW(winSize=35, maxDisparity=maxD, exact=False), _native.K_ASW_AGG),
          ("asw c3 consistent", ss.passive.StereoASW(winSize=35, maxDisparity=maxD, consistent=True), _native.K_ASW_AGG),
          ("gsw c4", ss.passive.StereoGSW(winSize=11, maxDisparity=maxD), _native.K_GSW_AGG)]
-for world, vrank in ((8, 3), (4, 1), (2, 0)):
+print(json.dumps({"TORCH_NCCL_HIGH_PRIORITY": os.environ["TORCH_NCCL_HIGH_PRIORITY"]}), flush=True)
+WORLDS = ((8, 3), (4, 1), (2, 0)) if len(sys.argv) < 2 else ((int(sys.argv[1]), int(sys.argv[2])),)
+for world, vrank in WORLDS:
     r0, r1 = strips.strip_bounds(H, world, vrank)
     ownL = torch.from_numpy(np.ascontiguousarray(L[r0:r1])).to(dev)
     ownR = torch.from_numpy(np.ascontiguousarray(R[r0:r1])).to(dev)
     for name, m, slot in cases:
         for overlap in (True, False):
-            os.environ["SSAMD_STRIP_OVERLAP"] = "1" if overlap else "0"
+            os.environ["SSAMD_STRIP_OVERLAP"] = "gsw" if overlap else "0"      # ("gsw": the default cut + StereoGSW, whose overlap is off by default)
             ctx = strips.StripContext(m, H, W, vrank, world, dev, loopback=True)
             for _ in range(3):
                 ctx.step(ownL, ownR, gather=False)
