@@ -108,6 +108,68 @@ struct AswArgs {
     AswGeom g;
 };
 
+// ---- the phase-shifted kernel's tiles of the headline configurations as COMPILE-TIME geometry (round 6) ------------------------
+// asw_aggregate_pipe_kernel<.., SLC, SRC, SEC> used to take only its three LDS strides as constants and read the other ~30 geometry
+// values from the kernel arguments: with the pointers and image sizes that is more scalars than the 102 SGPRs hold, and the compiler
+// spilled 76-155 of them into VGPR lanes (v_writelane / v_readlane).  The static instantiations now derive EVERYTHING from
+// (winSize, XG, DG, JC) at compile time -- a constexpr restatement of the pipe branch of asw_layout_e (ssamd_api.hip), which the
+// launcher compares field by field with the geometry it planned before it picks a static instantiation (asw_pipe_geom_matches).
+struct AswPipeTileId { int win, XG, DG, JC; };
+__host__ __device__ constexpr int asw_cx_round_up(int v, int m) { return (v + m - 1) / m * m; }
+__host__ __device__ constexpr int asw_cx_max(int a, int b) { return a > b ? a : b; }
+__host__ __device__ constexpr AswGeom asw_pipe_geom_constexpr(AswPipeTileId t)
+{
+    AswGeom g{};
+    const int win = t.win, p = win / 2;
+    g.Rx = 8; g.JC = t.JC; g.pipe = 1; g.wave_rx = 0; g.e2 = 1; g.nchunks = 1;
+    g.NC = (win + t.JC / 2) / t.JC;
+    g.JCmax = asw_cx_max(t.JC, win - (g.NC - 1) * t.JC);
+    g.XG = t.XG; g.DG = t.DG;
+    g.Tx = 8 * t.XG; g.Dc = ASW_RD * t.DG;
+    g.threads = asw_cx_round_up(t.XG * t.DG, 64);
+    g.dephase = g.threads / 64 >= 12 ? 1 : 0;
+    g.nL = g.Tx + 2 * p;
+    g.nRc = g.Tx + g.Dc - 1;
+    g.nR = g.nRc + 2 * p;
+    g.hL = 0; g.hR = 0;
+    g.SL = asw_cx_round_up(g.Tx, 4);
+    g.SR = asw_cx_round_up(g.nRc + 1, 4);
+    g.Se = 16 * ((t.DG + 3) / 4);
+    g.emask = 0;
+    const int wrows = 2 * g.JCmax;
+    int off = 0;
+    g.off_wL = off; off = (off + wrows * g.SL * 4 + 15) & ~15;
+    g.off_wR = off; off = (off + wrows * g.SR * 4 + 15) & ~15;
+    g.e_bytes = (g.nL * g.Se + 15) & ~15;
+    g.off_e = off; off = (off + g.e_bytes * 2 + 15) & ~15;
+    g.off_labL = off; off = (off + g.nL * 16 * 2 + 15) & ~15;
+    g.off_labR = off; off = (off + g.nR * 16 * 2 + 15) & ~15;
+    g.off_bestL = off; off = (off + g.Tx * 8 + 15) & ~15;
+    g.off_bestR = off; off = (off + (g.nRc + 1) * 8 + 15) & ~15;
+    g.off_cen = off; off = (off + (g.Tx + g.nRc) * 16 + 15) & ~15;
+    g.off_prox = off; off = (off + win * 4 * 2 + 15) & ~15;
+    g.lds_bytes_evol = off;
+    g.off_bgrL = off; off = (off + g.nL * 4 * 2 + 15) & ~15;
+    g.off_bgrR = off; off = (off + g.nR * 4 * 2 + 15) & ~15;
+    g.lds_bytes = off;
+    return g;
+}
+// tile of a static instantiation, by its three strides: 120 x 196 (1080p / D 0..192), 88 x 260 (4096 x 2160 / D 0..256), 216 x 68 (D 0..64)
+template <int SLC, int SRC, int SEC> struct AswPipeTile { static constexpr AswPipeTileId id{35, 1, 1, 16}; };        // (generic instantiation: never read)
+template <> struct AswPipeTile<120, 316, 208> { static constexpr AswPipeTileId id{35, 15, 49, 16}; };
+template <> struct AswPipeTile<88, 348, 272> { static constexpr AswPipeTileId id{35, 11, 65, 16}; };
+template <> struct AswPipeTile<216, 284, 80> { static constexpr AswPipeTileId id{35, 27, 17, 16}; };
+// every field the kernel reads (and the launch uses) equal?
+inline bool asw_pipe_geom_matches(const AswGeom &a, const AswGeom &b)
+{
+    return a.pipe == b.pipe && a.Rx == b.Rx && a.JC == b.JC && a.NC == b.NC && a.JCmax == b.JCmax && a.XG == b.XG && a.DG == b.DG && a.Tx == b.Tx &&
+           a.Dc == b.Dc && a.threads == b.threads && a.dephase == b.dephase && a.nL == b.nL && a.nRc == b.nRc && a.nR == b.nR && a.SL == b.SL &&
+           a.SR == b.SR && a.Se == b.Se && a.e_bytes == b.e_bytes && a.off_wL == b.off_wL && a.off_wR == b.off_wR && a.off_e == b.off_e &&
+           a.off_labL == b.off_labL && a.off_labR == b.off_labR && a.off_bestL == b.off_bestL && a.off_bestR == b.off_bestR &&
+           a.off_cen == b.off_cen && a.off_prox == b.off_prox && a.off_bgrL == b.off_bgrL && a.off_bgrR == b.off_bgrR &&
+           a.lds_bytes == b.lds_bytes && a.lds_bytes_evol == b.lds_bytes_evol && a.e2 == b.e2;
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // output row (of the sub-image) of workgroup row b

@@ -188,14 +188,21 @@ __global__ __launch_bounds__(256) void asw_prepass_kernel(const AswPrepassArgs P
 // compile-time constants for the launch geometries of the headline configurations (0: read from the geometry at run
 // time).  The eight steps of a trip then address their operands with immediate offsets from one pointer per array,
 // advanced once per trip: 3 address instructions per 8 steps instead of 24 (107 -> 104.4 VALU instructions per step).
-template <bool WITH_COSTS, int SLC = 0, int SRC = 0, int SEC = 0>
+// CG (round 6): the static instantiation takes the WHOLE tile geometry and the window from compile-time constants (see AswPipeTile);
+// false = strides only (rounds 3-5).  Both are built so that they can be compared in one process (SSAMD_ASW_STATIC=2 / 1).
+template <bool WITH_COSTS, int SLC = 0, int SRC = 0, int SEC = 0, bool CG = false>
 __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(const AswArgs A)
 {
     constexpr bool STATIC = SLC > 0;
+    static_assert(!CG || STATIC, "compile-time geometry belongs to a static tile");
     constexpr int RX = ASW_RX;
     constexpr int NWR = asw_nwr(RX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const AswGeom &g = A.g;
+    // static instantiations: the whole tile geometry and the window are compile-time constants (the launcher checked A.g against
+    // them: asw_pipe_geom_matches); the generic instantiation reads them from the arguments
+    constexpr AswGeom SG = asw_pipe_geom_constexpr(AswPipeTile<SLC, SRC, SEC>::id);
+    static_assert(!STATIC || (SG.SL == SLC && SG.SR == SRC && SG.Se == SEC), "the strides name the tile");
+    const AswGeom &g = CG ? SG : A.g;
     float *const wL = reinterpret_cast<float *>(smem + g.off_wL);
     float *const wR = reinterpret_cast<float *>(smem + g.off_wR);
     unsigned char *const eT0 = reinterpret_cast<unsigned char *>(smem + g.off_e);
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     float *const proxS = reinterpret_cast<float *>(smem + g.off_prox);
 
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int W = A.W, win = A.win, p = A.pad;
+    const int W = A.W, win = CG ? AswPipeTile<SLC, SRC, SEC>::id.win : A.win, p = CG ? AswPipeTile<SLC, SRC, SEC>::id.win / 2 : A.pad;
     const int Tx = g.Tx, Dc = g.Dc, nL = g.nL, nR = g.nR, nRc = g.nRc, SR = g.SR, Se = g.Se;
     const int JC = g.JC, NC = g.NC;
     int bx = blockIdx.x;                          // XCD-aware tile order, see asw_aggregate_kernel
@@ -491,10 +498,12 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     }
 
     int cb = 0;
+#pragma nounroll
     for (int i = i_lo; i < i_hi; ++i) {
         const unsigned char *const eT = eT0 + (i & 1) * g.e_bytes;
         AswRow ew[RX];
 
+#pragma nounroll                      // (NC is a compile-time 2 in the static instantiations: two copies of the tap loop cost VGPRs -> scratch)
         for (int c = 0; c < NC; ++c) {
 #ifndef SSAMD_ABLATE_BARRIER          // (ablation build: how much of the time is waiting at this barrier; results are wrong without it)
             __syncthreads();       // buffers of chunk (i, c) complete; every wave is done with chunk (i, c) - 1

@@ -8,6 +8,8 @@
 
 namespace ssamd {
 #define SSAMD_PIPE_INSTANCE(C, SL, SR, SE) template __global__ void asw_aggregate_pipe_kernel<C, SL, SR, SE>(const AswArgs);
+#define SSAMD_PIPE_INSTANCE_CG(C, SL, SR, SE) template __global__ void asw_aggregate_pipe_kernel<C, SL, SR, SE, true>(const AswArgs);
 #include "asw_instances.inc"
+#undef SSAMD_PIPE_INSTANCE_CG
 #undef SSAMD_PIPE_INSTANCE
 }  // namespace ssamd

@@ -27,9 +27,11 @@
 #ifndef SSAMD_SINGLE_TU          // (-DSSAMD_SINGLE_TU: everything in this translation unit, as until round 4: tools/build_variants.sh)
 namespace ssamd {
 #define SSAMD_PIPE_INSTANCE(C, SL, SR, SE) extern template __global__ void asw_aggregate_pipe_kernel<C, SL, SR, SE>(const AswArgs);
+#define SSAMD_PIPE_INSTANCE_CG(C, SL, SR, SE) extern template __global__ void asw_aggregate_pipe_kernel<C, SL, SR, SE, true>(const AswArgs);
 #define SSAMD_WAVE6_INSTANCE(C, K, CREG) extern template __global__ void asw_aggregate_wave6_kernel<C, K, CREG>(const AswWaveArgs);
 #include "asw_instances.inc"
 #undef SSAMD_PIPE_INSTANCE
+#undef SSAMD_PIPE_INSTANCE_CG
 #undef SSAMD_WAVE6_INSTANCE
 }  // namespace ssamd
 #endif
@@ -256,6 +258,7 @@ struct Ctx {
     long long evol_fallbacks = 0;       // calls that ran without the volume (in-kernel e tiles) or off the wave kernel for lack of memory
     long long tail_splits = 0;          // phase-shifted launches whose last partial round of workgroups ran as half-width tiles
     long long exact_calls = 0;          // ASW calls that ran the fp64 tie-break pass
+    long long static_tile_mismatch = 0; // pipe launches whose strides named a static tile that the full geometry did not match
     Profile prof;
 };
 
@@ -1299,10 +1302,19 @@ int asw_device_impl(Ctx &c, const uint8_t *dL, const uint8_t *dR, int H, int W, 
                 // strides known at compile time for the tiles of the headline configurations (immediate offsets in the
                 // tap steps): 120 x 196 (1080p / D 0..192) and 88 x 260 (4096 x 2160 / D 0..256), 216 x 68 (D 0..64)
                 // (with the cost / cost-image dump too: exact=True on the headline tiles ran the run-time-stride form, + 0.9 ms at 1080p / 193)
+                // SSAMD_ASW_STATIC=2 (round 6 experiment): instantiations that take the WHOLE tile geometry and the window from compile-time
+                // constants -- chosen only when the planned geometry equals the constexpr restatement field by field
                 if (tune().asw_static != 0) {
                     if (g.SL == 120 && g.SR == 316 && g.Se == 208) pk = d_costs ? asw_aggregate_pipe_kernel<true, 120, 316, 208> : asw_aggregate_pipe_kernel<false, 120, 316, 208>;
                     else if (g.SL == 88 && g.SR == 348 && g.Se == 272) pk = d_costs ? asw_aggregate_pipe_kernel<true, 88, 348, 272> : asw_aggregate_pipe_kernel<false, 88, 348, 272>;
                     else if (g.SL == 216 && g.SR == 284 && g.Se == 80) pk = d_costs ? asw_aggregate_pipe_kernel<true, 216, 284, 80> : asw_aggregate_pipe_kernel<false, 216, 284, 80>;
+                }
+                if (tune().asw_static == 2 && !d_costs) {
+                    auto is_tile = [&](AswPipeTileId id) { return win == id.win && asw_pipe_geom_matches(g, asw_pipe_geom_constexpr(id)); };
+                    if (is_tile(AswPipeTile<120, 316, 208>::id)) pk = asw_aggregate_pipe_kernel<false, 120, 316, 208, true>;
+                    else if (is_tile(AswPipeTile<88, 348, 272>::id)) pk = asw_aggregate_pipe_kernel<false, 88, 348, 272, true>;
+                    else if (is_tile(AswPipeTile<216, 284, 80>::id)) pk = asw_aggregate_pipe_kernel<false, 216, 284, 80, true>;
+                    else ++c.static_tile_mismatch;       // (counted: ssamd_counter "static_tile_mismatch")
                 }
                 const int pipe_lds = a.evol ? g.lds_bytes_evol : g.lds_bytes;          // (no staged colour bytes when the e tiles come from the volume)
                 if (pipe_lds > 160 * 1024) return fail(SSAMD_ELIMIT, "this tile needs the TAD volume (LDS %d bytes without it)", pipe_lds);
@@ -2015,6 +2027,7 @@ int ssamd_counter(int device, const char *name, long long *value)
     else if (n == "evol_bytes") *value = (long long)c->evol.cap;
     else if (n == "tail_splits") *value = c->tail_splits;
     else if (n == "exact_calls") *value = c->exact_calls;
+    else if (n == "static_tile_mismatch") *value = c->static_tile_mismatch;
     else if (n == "exact_entries" || n == "exact_flagged_left" || n == "exact_flagged_right" || n == "exact_overflow" || n == "exact_raw_entries") {
         // of the LAST exact call on this device: candidates re-evaluated in fp64, pixels with near-ties, whether the queue overflowed
         unsigned int ctr[5] = {0, 0, 0, 0, 0};
