@@ -441,7 +441,7 @@ def others(dev, seed):
     return res
 
 
-def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
+def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False, config="c3_1080p_d192_w35"):
     """The accuracy half of BASELINE.json's metric.  HEADLINE (`percent`, `exact_percent`, `pixels`): the GPU map of the
     WHOLE bench frame -- make_pair(1080, 1920, 192, seed=1), the frame the timed region runs -- against the map the
     unmodified reference computed for it (tests/golden/full_cases.npz F3p, or F3c with --consistent; generated once in the
@@ -466,7 +466,10 @@ def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
         fmaps = np.load(os.path.join(gdir, "full_cases.npz"))
         fmeta = json.load(open(os.path.join(gdir, "full_cases.json")))
     head = "F3c" if consistent else "F3p"
-    order = [c for c in (head, "F3c" if head == "F3p" else "F3p", "F4") if fmaps is not None and c in fmaps.files] + ["W3a", "W3b", "P2a"]
+    others_f = ("F3c" if head == "F3p" else "F3p", "F4")
+    if config == "c5_4k_d256_w35" and not consistent:      # --config c5_4k_d256_w35: the 4096 x 2160 frame against ITS reference map (round 6)
+        head, others_f = "F5p", ()
+    order = [c for c in (head,) + tuple(others_f) if fmaps is not None and c in fmaps.files] + ["W3a", "W3b", "P2a"]
     cases, frames = {}, {}
     for cid in order:
         if cid.startswith("F"):
@@ -489,7 +492,7 @@ def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
             m = pmeta[cid]
             a, b = np.ascontiguousarray(ppairs[m["pair"] + "_L"]), np.ascontiguousarray(ppairs[m["pair"] + "_R"])
             want, what = pmaps[cid], "photograph: tests/golden/photo_pairs.npz %s (reference examples/res/2 lawn pair, rectified, native width)" % m["pair"]
-        p = {k: v for k, v in m["params"].items() if k != "algo"}
+        p = {k: v for k, v in m["params"].items() if k not in ("algo", "frame")}
         gsw = m["params"]["algo"] == "gsw"
         matcher = ss.passive.StereoGSW(**p) if gsw else ss.passive.StereoASW(**p)
         if world > 1 and not gsw:
@@ -515,7 +518,7 @@ def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
         for flag in (True, False):
             try:
                 m = fmeta[head]
-                p = {k: v for k, v in m["params"].items() if k != "algo"}
+                p = {k: v for k, v in m["params"].items() if k not in ("algo", "frame")}
                 a, b = frames[tuple(m["frame"])]
                 d = ss.passive.StereoASW(exact=flag, **p).compute(a, b)
                 diff = np.abs(d.astype(np.int32) - fmaps[head].astype(np.int32))
@@ -535,8 +538,8 @@ def bad1_on_reference_strips(dev, rank=0, world=1, consistent=False):
         return {"percent": h["percent"], "exact_percent": h["exact_percent"], "pixels": h["pixels"], "bad1_pixels": h["bad1_pixels"],
                 "differing_pixels": h["differing_pixels"], "headline_case": head, "tie_exclusion": "none", "exact_mode": exact_mode, "fp32_mode": fp32_mode,
                 "cases": cases, "through": through,
-                "source": "tests/golden/full_cases.npz %s: the WHOLE frame of this run (make_pair(1080,1920,192,seed=1), D 0..192, win 35, "
-                          "consistent=%s) through the unmodified reference (_passive.cpp via oracle/_ref, "
+                "source": "tests/golden/full_cases.npz %s: the WHOLE frame of this run (config 3: make_pair(1080,1920,192,seed=1), D 0..192; config 5 / F5p: "
+                          "make_pair(2160,4096,256,seed=1), D 0..256; win 35, consistent=%s) through the unmodified reference (_passive.cpp via oracle/_ref, "
                           "tests/golden/make_golden_full.py), every pixel counted; cases: the other full-frame maps (F3c/F3p, "
                           "F4 = GSW config 4), the 72-row strips W3a / W3b of earlier rounds and a photograph (P2a)" % (head, consistent)}
     # (no full-frame golden in the tree: the strips of rounds 2-4)
@@ -738,6 +741,8 @@ def main():
     ap.add_argument("--config", default="c3_1080p_d192_w35", choices=sorted(CONFIGS))
     ap.add_argument("--consistent", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--fp32", action="store_true",
+                    help="time StereoASW(exact=False): the fp32 argmin without the fp64 tie-break pass (the default path of rounds 1-5); the line says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configurations (extra JSON key `others`)")
     ap.add_argument("--cpu-rows-per-thread", type=int, default=1,
@@ -822,7 +827,7 @@ def main():
     ownL = torch.from_numpy(np.ascontiguousarray(L[r0:r1])).to(dev)
     ownR = torch.from_numpy(np.ascontiguousarray(R[r0:r1])).to(dev)
     matcher = ss.passive.StereoASW(winSize=win, maxDisparity=maxD, minDisparity=minD, gammaC=GAMMA_C, gammaP=GAMMA_P,
-                                   consistent=args.consistent)
+                                   consistent=args.consistent, exact=False if args.fp32 else "auto")
 
     strip_ctx = strips.StripContext(matcher, H, W, rank, world, dev) if use_dist else None
     p2p_loopback = None
@@ -909,7 +914,7 @@ def main():
     if world > 1 and not args.no_bad1:
         # the accuracy half of the metric THROUGH the distributed path (every rank takes part; rank 0 keeps the figures)
         try:
-            bad1_dist = bad1_on_reference_strips(dev, rank, world, consistent=args.consistent)
+            bad1_dist = bad1_on_reference_strips(dev, rank, world, consistent=args.consistent, config=args.config)
         except Exception as e:      # noqa: BLE001
             bad1_dist = {"percent": None, "source": repr(e)[:200]}
 
@@ -979,10 +984,11 @@ def main():
             if bad1_dist is not None:
                 line["bad1_vs_cpu_ref"] = bad1_dist
         line["default_mode"] = ("exact: StereoASW(exact=\"auto\") -- near-ties of every winner selected in the aggregation kernel and re-decided in "
-                                "fp64 in the reference's arithmetic (DESIGN 4.7); the timed region runs this")
+                                "fp64 in the reference's arithmetic (DESIGN 4.7); the timed region runs this") if not args.fp32 else \
+                               "fp32 argmin only (--fp32: StereoASW(exact=False)); NOT the default path"
         if launches[_native.K_ASW_EXACT]:
             line["exact_pass_ms"] = ms[_native.K_ASW_EXACT] / max(1, args.steps)
-        if world == 1 and not use_dist:
+        if world == 1 and not use_dist and not args.fp32:
             # the same frame WITHOUT the tie-break pass (the default of rounds 1-5), alternating with the default so that both see the
             # same clocks: what the reference's own map costs
             try:
@@ -1025,7 +1031,7 @@ def main():
                 line["pointwise_kernels"] = {"error": repr(e)[:200]}
         if world == 1 and not use_dist and not args.no_bad1:
             try:
-                line["bad1_vs_cpu_ref"] = bad1_on_reference_strips(dev, consistent=args.consistent)
+                line["bad1_vs_cpu_ref"] = bad1_on_reference_strips(dev, consistent=args.consistent, config=args.config)
             except Exception as e:      # noqa: BLE001
                 line["bad1_vs_cpu_ref"] = {"percent": None, "source": repr(e)[:200]}
         if world == 1 and not use_dist and not args.no_e2e:

@@ -6,8 +6,11 @@ compiled where it lies into oracle/_ref) produced for the frame bench.py times, 
 F3p config 3 (ASW win 35, D 0..192), F3c the same with consistent=True, F4 config 4 (GSW class defaults, D 0..192).
 Generated once in the build container by tests/golden/make_golden_full.py (~1 h on 8 threads).
 
-Bars, with NO tie exclusion of any kind: ASW (fp32 kernels vs the fp64 reference) >= 99.5 % of all pixels within one
-level (north_star) and, tighter, >= 99 % identical; GSW: 0 mismatching pixels."""
+Round 6 adds F5p: config 5's frame, make_pair(2160, 4096, 256, seed=1), ASW win 35, D 0..256 (1.6 h of the reference's time).
+
+Bars, with NO tie exclusion of any kind: the default ASW path (near-ties re-decided in fp64) 0 mismatching pixels; the fp32
+argmin alone (exact=False) >= 99.5 % of all pixels within one level (north_star) and, tighter, >= 99 % identical; GSW: 0
+mismatching pixels."""
 import json
 import os
 
@@ -41,15 +44,50 @@ def test_asw_full_bench_frame_vs_reference(cid, full):
     if cid not in maps.files:
         pytest.skip("%s not generated (tests/golden/make_golden_full.py)" % cid)
     p = {k: v for k, v in meta[cid]["params"].items() if k != "algo"}
-    d = ss.passive.StereoASW(**p).compute(L, R)
     ref = maps[cid]
+    # the fp32 argmin alone (exact=False, the default path of rounds 1-5): north_star's bar and the tighter one
+    d = ss.passive.StereoASW(exact=False, **p).compute(L, R)
     assert d.shape == ref.shape == (1080, 1920) and d.dtype == np.int16
     diff, within1, exact = _stats(d, ref)
-    print("%s full frame, consistent=%s: %d pixels, exact %.5f %%, within-1 %.5f %%, bad-1.0 %.5f %% (%d pixels), differing %d" %
+    print("%s full frame, consistent=%s, fp32 argmin: %d pixels, exact %.5f %%, within-1 %.5f %%, bad-1.0 %.5f %% (%d pixels), differing %d" %
           (cid, p["consistent"], diff.size, 100 * exact, 100 * within1, 100 * (1 - within1), int(np.count_nonzero(diff > 1)),
            int(np.count_nonzero(diff))))
     assert within1 >= 0.995, (cid, within1)
     assert exact >= 0.99, (cid, exact)
+    # the default path (round 6: near-ties re-decided in fp64 in the reference's arithmetic): the reference's map itself
+    d = ss.passive.StereoASW(**p).compute(L, R)
+    n = int(np.count_nonzero(d != ref))
+    print("%s full frame, default path: %d of %d pixels differ from the reference" % (cid, n, d.size))
+    assert n == 0, (cid, n)
+
+
+def test_asw_config5_full_frame_vs_reference():
+    """BASELINE config 5 (4096 x 2160, D 0..256, win 35) on ONE GPU against the map the unmodified reference computed for the whole
+    frame (F5p: make_pair(2160, 4096, 256, seed=1), tests/golden/make_golden_full.py F5p, ~1.6 h of its time on 8 threads).
+    Default path: 0 differing pixels.  fp32 argmin alone: >= 99.5 % within one level, >= 99 % identical, no tie exclusion.
+    (The same frame cut into eight strips across eight processes: tests/test_gpu_strips_multiprocess.py.)"""
+    import simplestereo_amd as ss
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    maps = np.load(os.path.join(G, "full_cases.npz"))
+    if "F5p" not in maps.files:
+        pytest.skip("F5p not generated (tests/golden/make_golden_full.py F5p)")
+    meta = json.load(open(os.path.join(G, "full_cases.json")))["F5p"]
+    H, W, maxD, seed = meta["frame"]
+    L, R, _ = make_pair(H, W, maxD, seed)
+    p = {k: v for k, v in meta["params"].items() if k not in ("algo", "frame")}
+    ref = maps["F5p"]
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(L, R)
+    diff, within1, exact = _stats(d32, ref)
+    print("F5p 4096 x 2160 / 257, fp32 argmin: exact %.5f %%, bad-1.0 %.5f %% (%d pixels), differing %d of %d" %
+          (100 * exact, 100 * (1 - within1), int(np.count_nonzero(diff > 1)), int(np.count_nonzero(diff)), diff.size))
+    assert within1 >= 0.995 and exact >= 0.99
+    d = ss.passive.StereoASW(**p).compute(L, R)
+    n = int(np.count_nonzero(d != ref))
+    print("F5p default path: %d of %d pixels differ; %d candidates re-evaluated in fp64, overflow %d" %
+          (n, d.size, _native.counter("exact_entries"), _native.counter("exact_overflow")))
+    assert _native.counter("exact_overflow") == 0
+    assert n == 0, n
 
 
 def test_gsw_full_bench_frame_vs_reference_bit_exact(full):

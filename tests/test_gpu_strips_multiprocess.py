@@ -19,6 +19,14 @@ def _free_port():
     return port
 
 
+def _has_golden(cid):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_cases.npz")
+    try:
+        return cid in np.load(path).files
+    except OSError:
+        return False
+
+
 def _worker(rank, world, port, case, q):
     import torch
     import torch.distributed as dist
@@ -32,7 +40,7 @@ def _worker(rank, world, port, case, q):
         from simplestereo_amd import strips
         from simplestereo_amd.synth import make_pair
         algo, H, W, params = case
-        L, R, _ = make_pair(H, W, params["maxDisparity"], 11)
+        L, R, _ = make_pair(H, W, params["maxDisparity"], params.get("_seed", 11))
         dev = torch.device("cuda", 0)
         m = (ss.passive.StereoASW if algo == "asw" else ss.passive.StereoGSW)(**{k: v for k, v in params.items() if not k.startswith("_")})
         r0, r1 = strips.strip_bounds(H, world, rank)
@@ -43,7 +51,11 @@ def _worker(rank, world, port, case, q):
         full = None
         for _ in range(2):                                   # the context is reusable across frames
             full = ctx.step(ownL, ownR).cpu().numpy().copy()
-        want = m.compute(L, R)                               # whole frame, one process
+        if params.get("_golden"):
+            # the reference's own map of the whole frame (tests/golden/full_cases.npz, made by the unmodified _passive.cpp)
+            want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_cases.npz"))[params["_golden"]]
+        else:
+            want = m.compute(L, R)                           # whole frame, one process
         exp = params.get("_overlap")
         exp = exp[rank] if isinstance(exp, (list, tuple)) else exp
         q.put((rank, bool(np.array_equal(full, want)) and (exp is None or ctx.overlap == exp),
@@ -75,6 +87,10 @@ def _worker(rank, world, port, case, q):
     # BASELINE config 5's partition: eight ranks, 4096 columns, D 0..256, win 35 (the 88 x 260 tiles of the 4K launch); 136
     # rows = eight strips of 17 rows = exactly the halo, so every interior rank receives both halos whole from its neighbours
     (8, ("asw", 136, 4096, dict(winSize=35, maxDisparity=256))),
+    # round 6: BASELINE config 5 ITSELF -- the whole 4096 x 2160 frame, D 0..256, win 35, cut into eight strips, against the map the
+    # unmodified reference computed for it (F5p, 1.6 h of its time): every pixel equal
+    pytest.param(8, ("asw", 2160, 4096, dict(winSize=35, maxDisparity=256, _seed=1, _golden="F5p")),
+                 marks=pytest.mark.skipif(not _has_golden("F5p"), reason="F5p not generated (tests/golden/make_golden_full.py F5p)")),
 ])
 def test_strips_across_processes_reproduce_the_whole_frame(world, case):
     import torch.multiprocessing as mp

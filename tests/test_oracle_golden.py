@@ -194,9 +194,21 @@ def test_full_frame_golden_rows_reproduced_by_the_restatement():
     H, W, maxD, seed = meta["F3p"]["frame"]
     L, R, _ = make_pair(H, W, maxD, seed)
     import hashlib
+    frames = {tuple(meta["F3p"]["frame"]): (L, R)}
     for cid in maps.files:
+        key = tuple(meta[cid]["frame"])
+        if key not in frames:
+            frames[key] = make_pair(*key)[:2]
+        fl, fr = frames[key]
         assert hashlib.sha256(maps[cid].tobytes()).hexdigest() == meta[cid]["sha256"], cid
-        assert hashlib.sha256(L.tobytes() + R.tobytes()).hexdigest() == meta[cid]["input_sha256"], cid
+        assert hashlib.sha256(fl.tobytes() + fr.tobytes()).hexdigest() == meta[cid]["input_sha256"], cid
+    if "F5p" in maps.files:
+        # config 5's frame (4096 x 2160, D 0..256): two rows of the map through the restatement
+        q = {k: v for k, v in meta["F5p"]["params"].items() if k not in ("algo", "frame")}
+        fl, fr = frames[tuple(meta["F5p"]["frame"])]
+        pad5, r5, n5 = q["winSize"] // 2, 1211, 2
+        band5 = oracle.asw(np.ascontiguousarray(fl[r5 - pad5:r5 + n5 + pad5]), np.ascontiguousarray(fr[r5 - pad5:r5 + n5 + pad5]), hoist=True, **q)
+        assert np.array_equal(band5[pad5:pad5 + n5], maps["F5p"][r5:r5 + n5])
     p = {k: v for k, v in meta["F3p"]["params"].items() if k != "algo"}
     pad, r0, rows = p["winSize"] // 2, 536, 6
     band = oracle.asw(np.ascontiguousarray(L[r0 - pad:r0 + rows + pad]), np.ascontiguousarray(R[r0 - pad:r0 + rows + pad]), hoist=True, **p)
