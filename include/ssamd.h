@@ -285,7 +285,7 @@ int ssamd_debug_gsw_sqrt(int n, float *out);
 #define SSAMD_K_REMAP 5      /* rectification remap (bilinear)                    */
 #define SSAMD_K_REPROJECT 6  /* disparity -> 3-D points                           */
 #define SSAMD_K_ASW_ALT 7    /* alternate-rows mode: bounded search on the odd rows */
-#define SSAMD_K_ASW_EXACT 8  /* fp64 tie-break pass of ssamd_asw_exact*                */
+#define SSAMD_K_ASW_EXACT 8  /* fp64 tie-break pass of ssamd_asw_exact* (fp64 Lab, filter, winners, eval, resolve, patch) */
 #define SSAMD_K_COUNT 9
 int ssamd_profile_enable(int on);
 int ssamd_profile_reset(void);
@@ -305,7 +305,9 @@ int ssamd_set_option(const char *name, const char *value);
  * "evol_bytes": capacity of the volume buffer the context holds right now; "tail_splits": phase-shifted launches whose last
  * partial round of workgroups ran as half-width tiles; "exact_calls": ssamd_asw_exact* calls; of the LAST such call (these
  * synchronise the device): "exact_entries" candidates re-evaluated in fp64, "exact_flagged_left" / "exact_flagged_right"
- * pixels with near-ties, "exact_overflow" 1 when the candidate queue overflowed (the fp32 map was kept).
+ * pixels with near-ties, "exact_raw_entries" what the aggregation kernels of a merging call (several chunks / consistent) queued
+ * against their tile-local winners before the filter, "exact_overflow" 1 when a candidate queue overflowed (the fp32 map was
+ * kept); "static_tile_mismatch": SSAMD_ASW_STATIC=2 launches whose planned geometry did not equal a compile-time tile.
  * SSAMD_EINVAL for an unknown name. */
 int ssamd_counter(int device, const char *name, long long *value);
 
