@@ -16,5 +16,5 @@ from ._rigs import StereoRig, RectifiedStereoRig
 from . import strips
 from . import points
 
-__version__ = "0.5.0"
+__version__ = "0.6.0"
 __all__ = ["passive", "StereoRig", "RectifiedStereoRig", "strips", "points"]
