@@ -87,6 +87,7 @@ struct Tuning {
     int prepass_fuse = 1;             // 0: Lab records and TAD volume as two dependent launches (the form of rounds 2-4)
     int exact_tol = 128;              // fp64 tie-break pass: candidates within this many ulps of the winning cost image are re-evaluated
     int exact_cap = 0;                // 0 unset: queue capacity of the tie-break pass in entries (test hook: a tiny queue overflows)
+    int exact_rawcap = 0;             // 0 unset: capacity of the RAW queue of merging calls (test hook)
 };
 std::mutex g_tune_mutex;
 std::atomic<unsigned> g_tune_version{1};
@@ -119,6 +120,7 @@ bool tuning_assign(Tuning &t, const std::string &name, const char *v)
     else if (name == "SSAMD_ASW_PREPASS_FUSE") t.prepass_fuse = num(1);
     else if (name == "SSAMD_EXACT_TOL") t.exact_tol = v ? std::max(0, atoi(v)) : 128;
     else if (name == "SSAMD_EXACT_CAP") t.exact_cap = v ? std::max(1, atoi(v)) : 0;
+    else if (name == "SSAMD_EXACT_RAWCAP") t.exact_rawcap = v ? std::max(1, atoi(v)) : 0;
     else return false;
     return true;
 }
@@ -127,7 +129,7 @@ const char *const kTuningNames[] = {"SSAMD_ASW_GEOM", "SSAMD_GSW_GEOM", "SSAMD_A
                                     "SSAMD_ASW_WAVE", "SSAMD_ASW_WAVE_RX", "SSAMD_ASW_WAVE_WG", "SSAMD_ASW_WAVE_UNROLL",
                                     "SSAMD_ASW_WAVE_MERGE", "SSAMD_ASW_STATIC", "SSAMD_ASW_EVOL_MAX_MB", "SSAMD_ASW_WAVE_RD", "SSAMD_ASW_NO_E2", "SSAMD_ASW_XOR_ONLY", "SSAMD_MULTI_ALLOW_REPEAT",
                                     "SSAMD_ALT_QUEUE_CAP", "SSAMD_AUTOTUNE", "SSAMD_ASW_EVOL_FAIL", "SSAMD_ASW_TAIL", "SSAMD_ASW_WAVE_CREG", "SSAMD_ASW_LDS_RELAX",
-                                    "SSAMD_EXACT_TOL", "SSAMD_EXACT_CAP", "SSAMD_ASW_PREPASS_FUSE"};
+                                    "SSAMD_EXACT_TOL", "SSAMD_EXACT_CAP", "SSAMD_EXACT_RAWCAP", "SSAMD_ASW_PREPASS_FUSE"};
 
 std::map<std::string, std::string> g_tuning_env;      // what the process was started with: ssamd_set_option(name, NULL) goes back to THIS
 Tuning tuning_from_env()
@@ -940,6 +942,7 @@ int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, b
     // raw queue of merging calls (12 B per entry): what workgroups select against their tile-local winners
     size_t rawcap = direct ? 0 : std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(all_cands, (size_t)1 << 23)), (size_t)1 << 26);
     if (!direct && tune().exact_cap) rawcap = std::max<size_t>(rawcap, cap);
+    if (!direct && tune().exact_rawcap) rawcap = (size_t)tune().exact_rawcap;
     int rc;
     // [64 B counters][flagL nout][flagR nout]: one buffer, one memset
     if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(64 + 2 * nout)) ||

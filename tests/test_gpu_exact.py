@@ -157,6 +157,29 @@ def test_exact_mode_queue_overflow_keeps_the_fp32_map(ss):
     assert d64.shape == d32.shape
 
 
+def test_exact_mode_raw_queue_overflow_of_a_merging_call_keeps_the_fp32_map(ss):
+    """consistent=True goes through the RAW queue (tile-local near-ties + cost images) before the filter: a raw queue too small for
+    them (test hook SSAMD_EXACT_RAWCAP) must leave the fp32 map, count the overflow and warn -- every later kernel of the pass returns"""
+    import warnings
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(40, 300, 64, 9)
+    L = (L // 64 * 64).astype(np.uint8)                       # quantised colours: near-ties in every tile
+    p = dict(winSize=9, maxDisparity=64, consistent=True)
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(L, R)
+    with _native.options(SSAMD_EXACT_RAWCAP="3"):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            d = ss.passive.StereoASW(exact=True, **p).compute(L, R)
+        assert _native.counter("exact_overflow") == 1 and _native.counter("exact_raw_entries") > 3
+        assert any(issubclass(x.category, RuntimeWarning) for x in w)
+    assert np.array_equal(d, d32)
+    from oracle import oracle
+    d64 = ss.passive.StereoASW(exact=True, **p).compute(L, R)
+    assert _native.counter("exact_overflow") == 0 and _native.counter("exact_raw_entries") > 3
+    assert np.array_equal(d64, oracle.asw(L, R, **p))
+
+
 def test_exact_mode_argument_errors(ss):
     from simplestereo_amd.synth import make_pair
     L, R, _ = make_pair(24, 64, 8, 1)

@@ -20,6 +20,8 @@ for name, m in (("ASW", ss.passive.StereoASW(winSize=35, maxDisparity=maxd)), ("
     t = time.perf_counter(); d = m.compute(tL, tR); torch.cuda.synchronize(); dt = time.perf_counter() - t
     inner = d[pad:H - pad, shift + pad:W - pad - shift]
     ok = float((inner == shift).float().mean())
-    print("%s 7680x4320 D 0..%d: %.1f ms, interior == shift on %.4f %% of %d pixels; TAD volume %.2f GB, fallbacks %d" %
-          (name, maxd, dt * 1e3, 100 * ok, inner.numel(), _native.counter("evol_bytes") / 2**30, _native.counter("evol_fallbacks")), flush=True)
+    print("%s 7680x4320 D 0..%d: %.1f ms, interior == shift on %.4f %% of %d pixels; TAD volume %.2f GB, fallbacks %d; exact pass (default path): %d candidates re-evaluated, %d raw, overflow %d" %
+          (name, maxd, dt * 1e3, 100 * ok, inner.numel(), _native.counter("evol_bytes") / 2**30, _native.counter("evol_fallbacks"),
+           _native.counter("exact_entries") if name != "GSW" else 0, _native.counter("exact_raw_entries") if name != "GSW" else 0,
+           _native.counter("exact_overflow") if name != "GSW" else 0), flush=True)
     assert ok == 1.0
