@@ -96,11 +96,12 @@ __global__ __launch_bounds__(256) void asw_exact_filter_kernel(const AswExactArg
     for (unsigned e0 = blockIdx.x * blockDim.x; e0 < nloop; e0 += gridDim.x * blockDim.x) {
         const unsigned e = e0 + threadIdx.x;
         unsigned s2 = 0;
-        uint32_t pix = 0;
+        uint32_t pix = 0, rkey = 0xffffffffu;
         int d = 0;
         if (e < n) {
             const u64 ent = A.raw.entries[e];
             const uint32_t key = A.raw.ekeys[e];
+            rkey = key;
             pix = (uint32_t)ent;
             d = (int)((ent >> 32) & 0xffff);
             const unsigned sides = (unsigned)(ent >> 48) & 3u;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void asw_exact_filter_kernel(const AswExactArg
                 if ((uint32_t)g != pix % (uint32_t)A.W && (uint32_t)(g >> 32) < esc && exact_near(key, (uint32_t)(g >> 32), A.q.tol, A.q.sat_abs)) s2 |= EXACT_SIDE_R;
             }
         }
-        asw_exact_push_wave(A.q, s2 != 0, pix, d, s2);
+        asw_exact_push_wave(A.q, s2 != 0, pix, d, s2, rkey);
     }
 }
 
@@ -161,6 +162,141 @@ __global__ __launch_bounds__(256) void asw_exact_escalate_kernel(const AswExactA
     }
 }
 
+// 1d. Pixels with TWO OR MORE candidates whose fp32 cost is EXACTLY 0 (N = 0; marked by asw_exact_select / asw_exact_merge -- a lone zero,
+// the true match of a synthetic pair, needs nothing).  Candidates with image 0 are not queued: deep inside the black margins of a
+// rectified frame every candidate of a pixel is one -- 3e7 entries at 1080p.  The reference's cost of such a candidate is
+// exactly 0.0 iff every in-image tap has TAD = 0 (weights are positive in fp64), and costs are >= 0: if the fp32 winner -- the smallest
+// index among the candidates with image 0 -- passes that integer test, it IS the reference's first minimum (smaller indices have N > 0
+// in fp32, hence a positive cost in fp64) and the pixel is settled without a single fp64 operation.  If it does not (fp32 weights
+// that underflowed on taps with TAD > 0: small gammaC), the pixel gets ALL its candidates, as an escalated pixel does.
+// Workgroup = 64 consecutive pixels of one output row (most groups hold no such pixel and leave after one ballot).  The anchor image's
+// window rows of the whole segment are staged in LDS once, the other image's once per distinct disparity of the segment's zero-cost
+// winners (one, in a margin): a pixel's 1 225 compares then read LDS (a first form read them from HBM per pixel: + 7.5 ms on a 1080p
+// frame with margins).  side 0: anchors are left pixels x, the other image's column is x - d; side 1 (right-referenced winners): anchors
+// are right pixels, the other column is x + d.
+static constexpr int EXACT_ZSEG = 64, EXACT_ZWIN_MAX = 64;          // windows up to 63 x 63 go through LDS; larger ones take the escalation path
+__global__ __launch_bounds__(256) void asw_exact_zero_kernel(const AswExactArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char zsmem[];
+    const AswExactQueue &Q = A.q;
+    const int W = A.W, H = A.H, win = A.win, p = A.pad;
+    const int segs_per_row = (W + EXACT_ZSEG - 1) / EXACT_ZSEG;
+    const int tid = threadIdx.x;
+    const int TW = EXACT_ZSEG + 2 * p;                                  // tile columns
+    uint32_t *const tA = reinterpret_cast<uint32_t *>(zsmem);           // [win][TW] anchor image, bit 31 = outside the image
+    uint32_t *const tB = tA + win * TW;                                 // [win][TW] other image for the current disparity
+    __shared__ int s_idx[EXACT_ZSEG], s_state[EXACT_ZSEG];              // winner index; 0 not a zero-cost winner, 1 pending, 2 all-zero, 3 not all-zero
+    __shared__ int s_cur;
+    for (long long seg = blockIdx.x; seg < (long long)A.rows * segs_per_row; seg += gridDim.x) {
+        const int yr = (int)(seg / segs_per_row), x0 = (int)(seg - (long long)yr * segs_per_row) * EXACT_ZSEG, y = A.row0 + yr;
+        if (!Q.zrow[yr]) continue;                                      // no tile-local winner of this row costs exactly 0 (the usual case)
+        for (int side = 0; side < (A.keyR ? 2 : 1); ++side) {
+            __syncthreads();
+            if (tid < EXACT_ZSEG) {
+                const int x = x0 + tid;
+                bool z = false;
+                int idx = 0;
+                if (x < W) {
+                    const long long q = (long long)yr * W + x;
+                    if (side == 0) {                                    // marked by the aggregation kernels: two or more zero-cost candidates
+                        z = Q.zeroL[q] != 0;
+                        if (z) {
+                            if (A.keyL) { const u64 g = A.keyL[q]; z = g != KEY_NONE && (uint32_t)(g >> 32) == 0u; idx = (int)(uint32_t)g; }
+                            else idx = (int)A.disp[q];
+                        }
+                    } else {
+                        z = Q.zeroR[q] != 0;
+                        if (z) { const u64 g = A.keyR[q]; z = g != KEY_NONE && (uint32_t)(g >> 32) == 0u; idx = (int)(uint32_t)g; }
+                    }
+                }
+                s_idx[tid] = idx;
+                s_state[tid] = z ? 1 : 0;
+            }
+            if (__syncthreads_or(tid < EXACT_ZSEG && s_state[tid] == 1) == 0) continue;
+            if (win >= EXACT_ZWIN_MAX) {                                // (LDS tiles sized for windows below 64: larger ones are re-evaluated in fp64)
+                if (tid < EXACT_ZSEG && s_state[tid] == 1) s_state[tid] = 3;
+            } else {
+                const PixRec *const imgA = side ? A.recR : A.recL, *const imgB = side ? A.recL : A.recR;
+                // (tiles are staged eight loads at a time: one load per loop trip serialises on the HBM latency -- a first form spent 1.2 ms here)
+                auto stage = [&](uint32_t *tile, const PixRec *img, int shift) {
+                    for (int k0 = 0; k0 < win * TW; k0 += 8 * 256) {
+                        uint32_t v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int k = k0 + u * 256 + tid, i = k / TW, c = k - i * TW, ii = y - p + i, cc = x0 - p + c + shift;
+                            v[u] = (k < win * TW && (unsigned)ii < (unsigned)H && (unsigned)cc < (unsigned)W) ? img[(size_t)ii * W + cc].bgrx : 0x80000000u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int k = k0 + u * 256 + tid;
+                            if (k < win * TW) tile[k] = v[u];
+                        }
+                    }
+                };
+                stage(tA, imgA, 0);                                     // anchor tile: rows y - p .., columns x0 - p ..
+                for (;;) {
+                    __syncthreads();
+                    if (tid == 0) {
+                        int cur = -1;
+                        for (int k = 0; k < EXACT_ZSEG; ++k)
+                            if (s_state[k] == 1) { cur = side ? s_idx[k] - (x0 + k) : s_idx[k]; break; }
+                        s_cur = cur;                                    // disparity of the next pending pixel (-1: none left)
+                    }
+                    __syncthreads();
+                    const int d = s_cur;
+                    if (d < 0) break;
+                    const int shift = side ? d : -d;                    // other image's column = anchor column + shift
+                    stage(tB, imgB, shift);
+                    __syncthreads();
+                    // pixel = tid & 63, a quarter of the window rows per thread; taps outside either image are not taps (_passive.cpp:60-68)
+                    const int px = tid & (EXACT_ZSEG - 1), part = tid >> 6;
+                    const bool mine = s_state[px] == 1 && (side ? s_idx[px] - (x0 + px) : s_idx[px]) == d;
+                    bool nz = false;
+                    if (mine) {
+                        uint32_t acc = 0;                               // branch-free: (a ^ b) where both taps are inside their images
+                        for (int i = part; i < win; i += 4) {
+                            const uint32_t *const ra = tA + i * TW + px, *const rb = tB + i * TW + px;
+#pragma unroll 8
+                            for (int j = 0; j < win; ++j) {
+                                const uint32_t a = ra[j], b = rb[j];
+                                acc |= ((a | b) >> 31) ? 0u : (a ^ b);
+                            }
+                        }
+                        nz = acc != 0u;
+                    }
+                    __syncthreads();
+                    if (mine && part == 0) s_state[px] = 2;
+                    __syncthreads();
+                    if (mine && nz) s_state[px] = 3;                    // (any of the four parts)
+                }
+            }
+            __syncthreads();
+            if (tid < EXACT_ZSEG && s_state[tid] == 3) {
+                // not all-zero: every candidate of the pixel goes to the queue (rare: underflowed fp32 weights, or a window beyond 63)
+                const int xq = x0 + tid, widx = s_idx[tid];
+                const long long pq = (long long)yr * W + xq;
+                if (side == 0) {
+                    const int dhi = min(A.maxD, xq), cnt = dhi - A.minD;
+                    if (cnt > 0) {
+                        unsigned slot = atomicAdd(Q.counter, (unsigned)cnt);
+                        for (int d = A.minD; d <= dhi; ++d)
+                            if (d != widx) { if (slot < Q.cap) Q.entries[slot] = exact_entry((uint32_t)pq, d, EXACT_SIDE_L); ++slot; }
+                        Q.flagL[pq] = 1;
+                    }
+                } else {
+                    const int dhi = min(A.maxD, W - 1 - xq), cnt = dhi - A.minD;
+                    if (cnt > 0) {
+                        unsigned slot = atomicAdd(Q.counter, (unsigned)cnt);
+                        for (int d = A.minD; d <= dhi; ++d)
+                            if (xq + d != widx) { if (slot < Q.cap) Q.entries[slot] = exact_entry((uint32_t)(pq + d), d, EXACT_SIDE_R); ++slot; }
+                        Q.flagR[pq] = 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // 2. the winners of the flagged pixels join their near-ties in the queue; their result slots are initialised here (only
 // flagged pixels have entries, so nothing else is ever read: no 24 B / pixel memset)
 __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactArgs A)
@@ -178,7 +314,7 @@ __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactAr
         const int dwin = fl ? (A.keyL ? (int)(uint32_t)A.keyL[q] : (int)A.disp[q]) : 0;
         const u64 ml = __builtin_amdgcn_ballot_w64(fl);
         if (ml && fl && (int)__builtin_ctzll(ml) == (int)(threadIdx.x & 63)) atomicAdd(Q.counter + 1, (unsigned)__builtin_popcountll(ml));
-        asw_exact_push_wave(Q, fl, (uint32_t)q, dwin, EXACT_SIDE_L);
+        asw_exact_push_wave(Q, fl, (uint32_t)q, dwin, EXACT_SIDE_L, fl && A.keyL ? (uint32_t)(A.keyL[q] >> 32) : 0xffffffffu);
         if (A.keyR) {
             const bool fr = inb && Q.flagR[q];
             int xl = 0, xr = 0;
@@ -190,7 +326,7 @@ __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactAr
             }
             const u64 mr = __builtin_amdgcn_ballot_w64(fr);
             if (mr && fr && (int)__builtin_ctzll(mr) == (int)(threadIdx.x & 63)) atomicAdd(Q.counter + 2, (unsigned)__builtin_popcountll(mr));
-            asw_exact_push_wave(Q, fr, (uint32_t)(q + (xl - xr)), xl - xr, EXACT_SIDE_R);
+            asw_exact_push_wave(Q, fr, (uint32_t)(q + (xl - xr)), xl - xr, EXACT_SIDE_R, fr ? (uint32_t)(A.keyR[q] >> 32) : 0xffffffffu);
         }
     }
 }
@@ -232,7 +368,19 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
         const int ilo = max(0, p - y), ihi = min(win, H + p - y);
         const int ntap = (ihi - ilo) * ncol;
         double acc = 0.0;                           // lane 0: cost, lane 1: tot
-        for (int t0 = 0; t0 < ntap; t0 += EXACT_CHUNK) {
+        // entries whose fp32 cost is 0 (EXACT_HINT_ZERO): if every in-image tap has TAD = 0 the reference's cost is exactly 0.0 --
+        // `cost += w1*w2*0` for positive weights -- and nothing else has to be computed
+        bool all_zero = false;
+        if ((unsigned)(ent >> 48) & EXACT_HINT_ZERO) {
+            bool nz = false;
+            for (int t = lane; t < ntap; t += 64) {
+                const int q = t / ncol, i = ilo + q, j = jlo + (t - q * ncol);
+                const int ii = y - p + i, jj = xr - p + j, kk = x - p + j;
+                nz = nz || __builtin_amdgcn_sad_u8(A.recL[(size_t)ii * W + kk].bgrx, A.recR[(size_t)ii * W + jj].bgrx, 0u) != 0u;
+            }
+            all_zero = __builtin_amdgcn_ballot_w64(nz) == 0;
+        }
+        for (int t0 = 0; t0 < (all_zero ? 0 : ntap); t0 += EXACT_CHUNK) {
             const int nt = min(EXACT_CHUNK, ntap - t0);
             for (int t = lane; t < nt; t += 64) {
                 const int q = (t0 + t) / ncol, i = ilo + q, j = jlo + (t0 + t - q * ncol);
@@ -268,7 +416,7 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
         }
         const double tot = __shfl(acc, 1);
         if (lane == 0) {
-            const double c = acc / tot;
+            const double c = all_zero ? 0.0 : acc / tot;
             A.ecost[e] = c;
             const u64 bits = (u64)__double_as_longlong(c);           // costs are >= 0: the bit patterns order like the values
             if (sides & EXACT_SIDE_L) atomicMin(A.costL + pix, bits);

@@ -70,6 +70,10 @@ struct AswExactQueue {
     uint32_t *ekeys;             // RAW queue only: the fp32 cost image of each entry (what asw_exact_filter_kernel compares with the final winners)
     unsigned int *counter;       // entries appended (may exceed cap)
     unsigned char *flagL, *flagR;    // [rows][W] the pixel has near-ties (flagR null: no right-referenced pass; both null: RAW queue)
+    unsigned char *zeroL, *zeroR;    // [rows][W] the (left / right) pixel has TWO OR MORE candidates whose fp32 cost is exactly 0: asw_exact_zero_kernel
+                                     //   (a lone zero -- the true match of a synthetic pair -- needs nothing; zeroR null without a right pass)
+    unsigned char *zrow;             // [rows] the row holds such a pixel: only those rows are looked at
+    unsigned int W;                  // image width (row of a pixel index)
     unsigned int cap;
     uint32_t tol;                // cost-image ulps
     float sat_abs;               // absolute cost difference below which two saturated candidates are a near-tie of the reference's fp64
@@ -243,6 +247,10 @@ __device__ __forceinline__ uint32_t asw_cost_key(const float n, const float s, f
 
 // ---- exact mode: near-tie selection (shared by the four kernel families) ------------------------------------------------
 static constexpr unsigned EXACT_SIDE_L = 1u, EXACT_SIDE_R = 2u;
+// hint bit of a queue entry: the candidate's fp32 cost image is 0 (N = 0 exactly).  Black margins of rectified frames tie thousands
+// of such candidates per row; the fp64 cost of one is EXACTLY 0 iff every in-image tap has TAD = 0 (weights are positive in
+// fp64), which asw_exact_eval_kernel checks with integer compares before it spends ~2 500 fp64 exp / sqrt / div on the entry
+static constexpr unsigned EXACT_HINT_ZERO = 4u;
 // cost images (asw_cost_key) at or above this hold 40 - cost (cost > 20)
 static constexpr uint32_t EXACT_KEY_HIGH = 0xC0000000u - 0x41A00000u;      // 0x41A00000 = bits of 20.0f
 
@@ -285,8 +293,9 @@ __device__ __forceinline__ u64 exact_entry(uint32_t pix, int d, unsigned sides)
 // Append (pix, d, sides) for the lanes that `want` it.  Wave-aggregated: ONE atomicAdd on the queue counter per wave and call
 // (a flat or saturated frame makes every candidate a near-tie: per-lane atomics on one address would serialise the whole grid).
 // Every lane that reaches the call takes part; lanes that left the kernel earlier are simply not in the ballot.
-__device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool want, uint32_t pix, int d, unsigned sides, uint32_t key = 0)
+__device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool want, uint32_t pix, int d, unsigned sides, uint32_t key = 0xffffffffu)
 {
+    if (key == 0u) sides |= EXACT_HINT_ZERO;                  // (key unknown = 0xffffffff: no hint)
     const u64 mask = __builtin_amdgcn_ballot_w64(want);
     if (mask == 0) return;
     const int leader = (int)__builtin_ctzll(mask);
@@ -312,18 +321,25 @@ __device__ __forceinline__ void asw_exact_push_wave(const AswExactQueue &q, bool
 //   bL = &bestL[first column of the thread], bR = &bestR[slot of (first column, first disparity + RD - 1)] or nullptr,
 //   xb / db = first column / disparity of the tile, rowpix = (output row - row0) * W.
 // `live` = the lane holds candidates; EVERY lane of the wave calls this (wave-aggregated queue slots).
+template <int RX, int RD> struct AswKeyTile { uint32_t v[RX][RD]; };
+// (A __noinline__ form -- own register allocation, the 32 cost images by value -- was tried when the scan pushed three of the
+//  phase-shifted kernel's VGPRs into scratch: the by-value tile travels THROUGH scratch, + 0.9 ms per 1080p launch.  Inlined it is.)
 template <int RX, int RD>
-__device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool live, const uint32_t (&kk)[RX][RD],
+__device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool live, const AswKeyTile<RX, RD> &kt,
                                                  const u64 *bL, const u64 *bR, int xb, int db, uint32_t rowpix)
 {
+    const uint32_t (&kk)[RX][RD] = kt.v;
     static_assert(RX * RD <= 32, "one bit per candidate of the register tile");
     // Branch-free per candidate (a first form with short-circuit tests compiled to ~300 exec-mask branches per thread, a second one
     // with a per-candidate slow path cost + 1 ms on a 37 ms launch: a pixel without a good match has most of its candidates on
     // that path).  Rule (a) of exact_near for every candidate; rules (b), (c) and the local band only for the columns whose local
     // winner costs 17.5 or more -- one branch per column, skipped by waves that hold no such column.  Invalid candidates carry
-    // 0xffffffff and are masked out, and so are, in a merging call, candidates at or above q.deep (see AswExactQueue).
+    // 0xffffffff and are masked out, and so are, in a merging call, candidates at or above q.deep (see AswExactQueue) -- and candidates
+    // whose image is 0 (cost exactly 0: they can only tie a winner that costs 0 too; the black margins of a rectified 1080p frame are
+    // 3e7 of them; asw_exact_zero_kernel settles those pixels with integer compares).
     uint32_t mL = 0, mR = 0;
     if (live) {
+        uint32_t zl = 0, zr = 0;
         const uint32_t tol = q.tol, deep = q.deep;
         const float ctol = 20.0f * 1.1920929e-7f * (float)tol, sat_abs = q.sat_abs;
         auto slow = [&](uint32_t key, uint32_t kh) -> uint32_t {             // exact_near_local without its rule (a), as 0 / 1
@@ -343,9 +359,10 @@ __device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool li
 #pragma unroll
             for (int di = 0; di < RD; ++di) {
                 const uint32_t key = kk[xi][di];
-                const uint32_t ok = (key < deep ? 1u : 0u) & (wd != (uint32_t)di ? 1u : 0u);
+                const uint32_t ok = (key < deep ? 1u : 0u) & (key != 0u ? 1u : 0u) & (wd != (uint32_t)di ? 1u : 0u);
                 okm |= ok << di;
                 mL |= (ok & (key - kh <= tol ? 1u : 0u)) << (xi * RD + di);
+                zl |= ((key == 0u ? 1u : 0u) & (wd != (uint32_t)di ? 1u : 0u)) << xi;       // a second candidate that costs exactly 0
             }
             if (kh >= 0x418C0000u && kh != 0xffffffffu) {                       // 17.5f
 #pragma unroll
@@ -364,13 +381,20 @@ __device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool li
                     const int di = xi + RD - 1 - k;
                     if (di >= 0 && di < RD) {                                   // (compile time)
                         const uint32_t key = kk[xi][di];
-                        const uint32_t ok = (key < deep ? 1u : 0u) & (wx != (uint32_t)xi ? 1u : 0u);
+                        const uint32_t ok = (key < deep ? 1u : 0u) & (key != 0u ? 1u : 0u) & (wx != (uint32_t)xi ? 1u : 0u);
                         uint32_t near = key - kh <= tol ? 1u : 0u;
                         if (high) near |= slow(key, kh);
                         mR |= (ok & near) << (xi * RD + di);
+                        zr |= ((key == 0u ? 1u : 0u) & (wx != (uint32_t)xi ? 1u : 0u)) << k;
                     }
                 }
             }
+        }
+        // pixels with two or more zero-cost candidates (black margins): marked for asw_exact_zero_kernel; rare, a few byte stores
+        if (zl | zr) {
+            q.zrow[rowpix / q.W] = 1;
+            for (uint32_t z = zl; z; z &= z - 1) q.zeroL[rowpix + (uint32_t)(xb + __builtin_ctz(z))] = 1;
+            for (uint32_t z = zr; z; z &= z - 1) q.zeroR[rowpix + (uint32_t)(xb - db - RD + 1 + __builtin_ctz(z))] = 1;      // right column of slot k: xb + xi - (db + di), k = xi - di + RD - 1
         }
     }
     // Queue slots: ONE returning atomic per wave (a first form took one per round of the busiest lane: the round trips, at the end
@@ -402,16 +426,14 @@ __device__ __forceinline__ void asw_exact_select(const AswExactQueue &q, bool li
         const uint32_t pix = rowpix + (uint32_t)(xb + xi);
         const int d = db + di;
         if (slot < q.cap) {
-            q.entries[slot] = exact_entry(pix, d, sides);
-            if (q.ekeys) {
-                uint32_t key = 0;
+            uint32_t key = 0;
 #pragma unroll
-                for (int a = 0; a < RX; ++a)
+            for (int a = 0; a < RX; ++a)
 #pragma unroll
-                    for (int c2 = 0; c2 < RD; ++c2)
-                        if (a * RD + c2 == b) key = kk[a][c2];
-                q.ekeys[slot] = key;
-            }
+                for (int c2 = 0; c2 < RD; ++c2)
+                    if (a * RD + c2 == b) key = kk[a][c2];
+            q.entries[slot] = exact_entry(pix, d, sides | (key == 0u ? EXACT_HINT_ZERO : 0u));
+            if (q.ekeys) q.ekeys[slot] = key;
         }
         if ((sides & EXACT_SIDE_L) && q.flagL) q.flagL[pix] = 1;
         if ((sides & EXACT_SIDE_R) && q.flagR) q.flagR[pix - (uint32_t)d] = 1;
@@ -432,12 +454,17 @@ __device__ __forceinline__ void asw_exact_merge(const AswExactQueue &q, bool hav
     int d = 0;
     if (have && old != KEY_NONE) {
         const u64 lo = mine < old ? mine : old, hi = mine < old ? old : mine;
-        if ((uint32_t)(hi >> 32) < q.deep && exact_near_local((uint32_t)(hi >> 32), (uint32_t)(lo >> 32), q.tol, q.sat_abs)) {
+        if ((uint32_t)(hi >> 32) < q.deep && (uint32_t)(hi >> 32) != 0u && exact_near_local((uint32_t)(hi >> 32), (uint32_t)(lo >> 32), q.tol, q.sat_abs)) {
             want = true;
             key = (uint32_t)(hi >> 32);
             if (RIGHT) { const int xl = (int)(uint32_t)hi; pix = rowpix + (uint32_t)xl; d = xl - xcol; }
             else { pix = rowpix + (uint32_t)xcol; d = (int)(uint32_t)hi; }
         }
+    }
+    if (have && old != KEY_NONE && (uint32_t)(old >> 32) == 0u && (uint32_t)(mine >> 32) == 0u) {
+        // two tiles' winners both cost exactly 0: the pixel has two zero-cost candidates (asw_exact_zero_kernel)
+        (RIGHT ? q.zeroR : q.zeroL)[rowpix + (uint32_t)xcol] = 1;
+        q.zrow[rowpix / q.W] = 1;
     }
     asw_exact_push_wave(q, want, pix, d, RIGHT ? EXACT_SIDE_R : EXACT_SIDE_L, key);
 }
@@ -772,7 +799,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     // ---- weighted average (_passive.cpp:88) and the two WTA reductions
     int tidf = threadIdx.x;
     asm volatile("" : "+v"(tidf));
-    uint32_t kk[RX][ASW_RD];                      // cost images of the register tile (exact mode re-reads them after the barrier)
+    AswKeyTile<RX, ASW_RD> kt;                      // cost images of the register tile (exact mode re-reads them after the barrier)
     if (tidf < g.XG * g.DG) {
         const int xg = tidf % g.XG, dg = tidf / g.XG;
         u64 diag[RX + ASW_RD - 1];
@@ -786,11 +813,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
             for (int di = 0; di < ASW_RD; ++di) {
                 const int d = dlo + ASW_RD * dg + di;
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
-                kk[xi][di] = 0xffffffffu;
+                kt.v[xi][di] = 0xffffffffu;
                 if (valid) {
                     float c;
                     const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
-                    kk[xi][di] = (uint32_t)(hi >> 32);
+                    kt.v[xi][di] = (uint32_t)(hi >> 32);
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
@@ -812,7 +839,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, RX == 8 ? 3 : 4) void asw_aggregat
     if (xq) {
         const bool live = tidf < g.XG * g.DG;
         const int xg = live ? tidf % g.XG : 0, dg = live ? tidf / g.XG : 0;
-        asw_exact_select<RX, ASW_RD>(A.xq, live, kk, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
+        asw_exact_select<RX, ASW_RD>(A.xq, live, kt, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
                                      x0 + RX * xg, dlo + ASW_RD * dg, (uint32_t)orow);
     }
     if (A.disp) {

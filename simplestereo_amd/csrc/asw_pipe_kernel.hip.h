@@ -577,7 +577,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     // ---- weighted average (_passive.cpp:88) and the two WTA reductions (as asw_aggregate_kernel)
     int tidf = threadIdx.x;
     asm volatile("" : "+v"(tidf));
-    uint32_t kk[RX][ASW_RD];                      // cost images of the register tile (exact mode re-reads them after the barrier)
+    AswKeyTile<RX, ASW_RD> kt;                      // cost images of the register tile (exact mode re-reads them after the barrier)
     if (tidf < nact) {
         const int xg = pk_xd & 0xffff, dg = pk_xd >> 16;
         u64 diag[RX + ASW_RD - 1];
@@ -591,11 +591,11 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
             for (int di = 0; di < ASW_RD; ++di) {
                 const int d = dlo + ASW_RD * dg + di;
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
-                kk[xi][di] = 0xffffffffu;
+                kt.v[xi][di] = 0xffffffffu;
                 if (valid) {
                     float c;
                     const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
-                    kk[xi][di] = (uint32_t)(hi >> 32);
+                    kt.v[xi][di] = (uint32_t)(hi >> 32);
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(ASW_MAX_THREADS, 3) void asw_aggregate_pipe_kernel(
     const bool xq = !WITH_COSTS && A.xq.entries != nullptr;          // exact mode: near-ties of the winners go to the fp64 pass's queue
     if (xq) {
         const int xg = pk_xd & 0xffff, dg = pk_xd >> 16;
-        asw_exact_select<RX, ASW_RD>(A.xq, tidf < nact, kk, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
+        asw_exact_select<RX, ASW_RD>(A.xq, tidf < nact, kt, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
                                      x0 + RX * xg, dlo + ASW_RD * dg, (uint32_t)orow);
     }
     if (A.disp) {

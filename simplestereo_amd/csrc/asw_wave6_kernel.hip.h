@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
     for (int k = lane; k < Txw; k += 64) bestL[k] = KEY_NONE;        // (these share the pixel rows' space)
     for (int k = lane; k <= nRcw; k += 64) bestR[k] = KEY_NONE;
     asw_wave_sync();
-    uint32_t kk[RX][RD];                      // cost images of the register tile (exact mode re-reads them after the wave's barrier)
+    AswKeyTile<RX, RD> kt;                      // cost images of the register tile (exact mode re-reads them after the wave's barrier)
     if (active) {
         u64 diag[RX + RD - 1];
 #pragma unroll
@@ -267,11 +267,11 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
             for (int di = 0; di < RD; ++di) {
                 const int d = dlo + RD * dg + di;
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
-                kk[xi][di] = 0xffffffffu;
+                kt.v[xi][di] = 0xffffffffu;
                 if (valid) {
                     float c;
                     const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
-                    kk[xi][di] = (uint32_t)(hi >> 32);
+                    kt.v[xi][di] = (uint32_t)(hi >> 32);
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + RD - 1] = min(diag[xi - di + RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void asw_aggregate_wave6_kernel(const AswWa
     asw_wave_sync();
     const bool xq = !WITH_COSTS && A.xq.entries != nullptr;          // exact mode: near-ties of the winners go to the fp64 pass's queue
     if (xq)
-        asw_exact_select<RX, RD>(A.xq, active, kk, bestL + RX * xg, A.keyR ? bestR + (RX * xg - RD * dg + Dc - RD) : nullptr,
+        asw_exact_select<RX, RD>(A.xq, active, kt, bestL + RX * xg, A.keyR ? bestR + (RX * xg - RD * dg + Dc - RD) : nullptr,
                                  x0 + RX * xg, dlo + RD * dg, (uint32_t)orow);
     if (A.disp) {
         for (int k = lane; k < Txw; k += 64) {

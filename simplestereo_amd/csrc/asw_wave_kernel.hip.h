@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
     for (int k = lane; k < Txw; k += 64) bestL[k] = KEY_NONE;        // (these share the pixel rows' space)
     for (int k = lane; k <= nRcw; k += 64) bestR[k] = KEY_NONE;
     asw_wave_sync();
-    uint32_t kk[RX][ASW_RD];                      // cost images of the register tile (exact mode re-reads them after the wave's barrier)
+    AswKeyTile<RX, ASW_RD> kt;                      // cost images of the register tile (exact mode re-reads them after the wave's barrier)
     if (active) {
         u64 diag[RX + ASW_RD - 1];
 #pragma unroll
@@ -444,11 +444,11 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
             for (int di = 0; di < ASW_RD; ++di) {
                 const int d = dlo + ASW_RD * dg + di;
                 const bool valid = (x < W) && (d <= A.maxD) && (x - d >= 0);
-                kk[xi][di] = 0xffffffffu;
+                kt.v[xi][di] = 0xffffffffu;
                 if (valid) {
                     float c;
                     const u64 hi = (u64)asw_cost_key(accN[xi][di], accS[xi][di], c) << 32;
-                    kk[xi][di] = (uint32_t)(hi >> 32);
+                    kt.v[xi][di] = (uint32_t)(hi >> 32);
                     bl = min(bl, hi | (u64)(uint32_t)d);
                     diag[xi - di + ASW_RD - 1] = min(diag[xi - di + ASW_RD - 1], hi | (u64)(uint32_t)x);
                     if (WITH_COSTS)
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, RX == 8 ? SSAMD_WAVE8_OCC : SSAMD_WAVE4_OCC) v
     asw_wave_sync();
     const bool xq = !WITH_COSTS && A.xq.entries != nullptr;          // exact mode: near-ties of the winners go to the fp64 pass's queue
     if (xq)
-        asw_exact_select<RX, ASW_RD>(A.xq, active, kk, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
+        asw_exact_select<RX, ASW_RD>(A.xq, active, kt, bestL + RX * xg, A.keyR ? bestR + (RX * xg - ASW_RD * dg + Dc - ASW_RD) : nullptr,
                                  x0 + RX * xg, dlo + ASW_RD * dg, (uint32_t)orow);
     if (A.disp) {
         for (int k = lane; k < Txw; k += 64) {

@@ -937,25 +937,29 @@ int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, b
     // for every one of them on both sides -- a flat test image cannot overflow
     // (a candidate can be queued once per side -- by a select and by a merge, or by the left and the right escalation)
     const size_t all_cands = 2 * (nout * (size_t)nD + nout);
-    size_t cap = std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(all_cands, (size_t)1 << 23)), (size_t)1 << 25);
+    size_t cap = std::min<size_t>(std::max<size_t>(4 * nout, std::min<size_t>(all_cands, (size_t)1 << 23)), (size_t)1 << 26);
     if (tune().exact_cap) cap = (size_t)tune().exact_cap;
     // raw queue of merging calls (12 B per entry): what workgroups select against their tile-local winners
     size_t rawcap = direct ? 0 : std::min<size_t>(std::max<size_t>(2 * nout, std::min<size_t>(all_cands, (size_t)1 << 23)), (size_t)1 << 26);
     if (!direct && tune().exact_cap) rawcap = std::max<size_t>(rawcap, cap);
     if (!direct && tune().exact_rawcap) rawcap = (size_t)tune().exact_rawcap;
     int rc;
-    // [64 B counters][flagL nout][flagR nout]: one buffer, one memset
-    if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(64 + 2 * nout)) ||
+    // [64 B counters][flagL][flagR][zeroL][zeroR] (nout bytes each) [zrow rows]: one buffer, one memset
+    if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(64 + 4 * nout + (size_t)rows)) ||
         (rc = c.xslots.reserve(nout * 24)) || (rawcap && (rc = c.xraw.reserve(rawcap * 12))))
         return rc;
     c.xcap = (unsigned int)cap;
     c.xrawcap = (unsigned int)rawcap;
-    HIP_TRY(hipMemsetAsync(c.xflags.ptr, 0, 64 + (consistent ? 2 : 1) * nout, s));
+    HIP_TRY(hipMemsetAsync(c.xflags.ptr, 0, 64 + 4 * nout + (size_t)rows, s));
     q.entries = (u64 *)c.xqueue.ptr;
     q.ekeys = nullptr;
     q.counter = (unsigned int *)c.xflags.ptr;
     q.flagL = (unsigned char *)c.xflags.ptr + 64;
     q.flagR = consistent ? q.flagL + nout : nullptr;
+    q.zeroL = q.flagL + 2 * nout;
+    q.zeroR = consistent ? q.flagL + 3 * nout : nullptr;
+    q.zrow = q.flagL + 4 * nout;
+    q.W = (unsigned int)W;
     q.cap = (unsigned int)cap;
     // Near-tie band.  128 ulps = 1.5e-5 relative at gammaC = 5 and a 35 x 35 window: the kernels' support weights inherit the
     // rounding of the Lab records to float (|dLab| <= ~1.3e-5 per colour distance), i.e. a relative error of ~2.6e-5 / gammaC on a
@@ -1019,6 +1023,13 @@ int asw_exact_pass(Ctx &c, const AswExactQueue &q, const AswExactQueue &raw, int
     if (raw.entries) {
         hipLaunchKernelGGL(asw_exact_filter_kernel, dim3(256 * 8), dim3(256), 0, s, x);
         hipLaunchKernelGGL(asw_exact_escalate_kernel, dim3(pb), dim3(256), 0, s, x);
+    }
+    {
+        const int zwin = std::min(win, EXACT_ZWIN_MAX - 1);
+        const size_t zlds = (size_t)2 * zwin * (EXACT_ZSEG + 2 * (zwin / 2)) * 4;                      // two window-row tiles (<= 63 x 126 x 4 B x 2)
+        if ((rc = grant_dyn_lds(c, (const void *)asw_exact_zero_kernel, (int)zlds))) return rc;
+        const long long segs = (long long)rows * ((W + EXACT_ZSEG - 1) / EXACT_ZSEG);
+        hipLaunchKernelGGL(asw_exact_zero_kernel, dim3((unsigned)std::min<long long>(segs, 256 * 64)), dim3(256), zlds, s, x);
     }
     hipLaunchKernelGGL(asw_exact_winners_kernel, dim3(pb), dim3(256), 0, s, x);
     hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 6), dim3(64 * EXACT_WAVES), 0, s, x);

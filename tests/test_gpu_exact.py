@@ -180,6 +180,55 @@ def test_exact_mode_raw_queue_overflow_of_a_merging_call_keeps_the_fp32_map(ss):
     assert np.array_equal(d64, oracle.asw(L, R, **p))
 
 
+@pytest.mark.parametrize("cons", [False, True])
+def test_black_margins_of_rectified_frames(cons, ss):
+    """rectified frames carry black margins: deep inside them every candidate of a pixel costs exactly 0 and ties every other -- a first
+    form of the in-kernel selection queued 3e7 of them on a 1080p frame (overflow: the whole frame fell back to the fp32 map).  Such
+    candidates are no longer queued: a pixel whose fp32 winner costs exactly 0 is settled by asw_exact_zero_kernel with integer compares
+    (all taps TAD = 0 => the reference's cost is exactly 0.0 and the smallest such index is its first minimum).  Same map as the oracle,
+    a short queue, no overflow."""
+    from oracle import oracle
+    from simplestereo_amd import _native
+    from simplestereo_amd.synth import make_pair
+    L, R, _ = make_pair(48, 420, 64, 31)
+    L[:, :150] = 0; R[:, :150] = 0                       # a black band on the left of both views
+    L[:6] = 0; R[:6] = 0                                 # ... and along the top
+    L[:, 400:] = 0                                       # the left view also on the right (the right view keeps its content there)
+    L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+    p = dict(winSize=15, maxDisparity=64, minDisparity=0, consistent=cons)
+    d = ss.passive.StereoASW(**p).compute(L, R)
+    n = _native.counter("exact_entries")
+    assert _native.counter("exact_overflow") == 0
+    ref = oracle.asw(L, R, **p)
+    zero_cost_pixels = int(np.count_nonzero((L[:, :, 0] == 0) & (d >= 0)))
+    print("black margins, consistent=%s: %d candidates in the queue, %d pixels differ from the oracle" % (cons, n, int(np.count_nonzero(d != ref))))
+    assert n < 40000 and zero_cost_pixels > 5000         # (the first form queued 367 072 here)
+    assert np.array_equal(d, ref)
+
+
+@pytest.mark.parametrize("cons", [False, True])
+def test_zero_cost_winners_whose_weights_underflow(cons, ss):
+    """the other branch of asw_exact_zero_kernel: with a tiny gammaC the fp32 weights of taps with TAD > 0 underflow to 0, so a candidate's
+    fp32 cost is exactly 0 although its window is NOT all-zero -- the reference's fp64 cost is positive.  Such pixels get all their
+    candidates re-evaluated; the map is the oracle's."""
+    from oracle import oracle
+    from simplestereo_amd import _native
+    rng = np.random.default_rng(77)
+    H, W = 30, 160
+    L = np.zeros((H, W, 3), np.uint8); R = np.zeros((H, W, 3), np.uint8)
+    L[:, :, :] = rng.integers(0, 2, (H, W, 1)) * 255          # black / white speckle: Lab distances of 100 between neighbours
+    R[:, :-3] = L[:, 3:]                                      # shifted by 3; elsewhere black
+    L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+    p = dict(winSize=9, maxDisparity=12, minDisparity=0, consistent=cons, gammaC=0.7, gammaP=17.5)
+    d = ss.passive.StereoASW(**p).compute(L, R)
+    assert _native.counter("exact_overflow") == 0
+    ref = oracle.asw(L, R, **p)
+    d32 = ss.passive.StereoASW(exact=False, **p).compute(L, R)
+    print("underflowing weights, consistent=%s: exact %d, fp32 %d pixels differ from the oracle; %d candidates re-evaluated" %
+          (cons, int(np.count_nonzero(d != ref)), int(np.count_nonzero(d32 != ref)), _native.counter("exact_entries")))
+    assert np.array_equal(d, ref)
+
+
 def test_exact_mode_argument_errors(ss):
     from simplestereo_amd.synth import make_pair
     L, R, _ = make_pair(24, 64, 8, 1)
