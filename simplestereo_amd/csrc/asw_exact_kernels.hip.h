@@ -48,6 +48,12 @@ struct AswExactArgs {
     double *ecost;                   // [cap] fp64 cost of each entry
     u64 *costL, *costR;              // [rows][W] minimum fp64 cost bits over the pixel's entries (initialised for flagged pixels)
     uint32_t *idxL, *idxR;           // [rows][W] smallest index among the entries at that minimum
+    // weight tables of flagged pixels (asw_exact_wtab_kernel): the ~180 queue entries of a flagged left pixel share their LEFT support
+    // weights (w1 depends on the left pixel only, _passive.cpp:47-50), those of a flagged right pixel their right ones
+    uint32_t *wslotL, *wslotR;       // [rows][W] table slot of a flagged pixel (written for flagged pixels only; >= wcap: none)
+    uint32_t *wpix;                  // [wcap] pixel | side << 31 of each slot
+    double *wtab;                    // [wcap][win * win] prox * exp(-dLab / gammaC) towards the slot's centre pixel, 0 outside the image
+    unsigned int wcap;               // slots available (counter[6] = slots asked for)
     int H, W, win, pad, minD, maxD, row0, rows;
     double gammaC;
 };
@@ -297,6 +303,22 @@ __global__ __launch_bounds__(256) void asw_exact_zero_kernel(const AswExactArgs 
     }
 }
 
+// a weight-table slot for every flagged pixel of the wave (mask = ballot(flagged)): one atomic per wave
+__device__ __forceinline__ void exact_assign_wslot(const AswExactArgs &A, bool flagged, u64 mask, uint32_t pix, uint32_t side)
+{
+    if (mask == 0 || A.wcap == 0) return;
+    const int leader = (int)__builtin_ctzll(mask);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(A.q.counter + 6, (unsigned)__builtin_popcountll(mask));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+    if (flagged) {
+        const unsigned slot = base + (unsigned)__builtin_popcountll(mask & (((u64)1 << lane) - 1));
+        (side ? A.wslotR : A.wslotL)[pix] = slot;
+        if (slot < A.wcap) A.wpix[slot] = pix | (side << 31);
+    }
+}
+
 // 2. the winners of the flagged pixels join their near-ties in the queue; their result slots are initialised here (only
 // flagged pixels have entries, so nothing else is ever read: no 24 B / pixel memset)
 __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactArgs A)
@@ -314,6 +336,7 @@ __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactAr
         const int dwin = fl ? (A.keyL ? (int)(uint32_t)A.keyL[q] : (int)A.disp[q]) : 0;
         const u64 ml = __builtin_amdgcn_ballot_w64(fl);
         if (ml && fl && (int)__builtin_ctzll(ml) == (int)(threadIdx.x & 63)) atomicAdd(Q.counter + 1, (unsigned)__builtin_popcountll(ml));
+        exact_assign_wslot(A, fl, ml, (uint32_t)q, 0u);
         asw_exact_push_wave(Q, fl, (uint32_t)q, dwin, EXACT_SIDE_L, fl && A.keyL ? (uint32_t)(A.keyL[q] >> 32) : 0xffffffffu);
         if (A.keyR) {
             const bool fr = inb && Q.flagR[q];
@@ -326,7 +349,40 @@ __global__ __launch_bounds__(256) void asw_exact_winners_kernel(const AswExactAr
             }
             const u64 mr = __builtin_amdgcn_ballot_w64(fr);
             if (mr && fr && (int)__builtin_ctzll(mr) == (int)(threadIdx.x & 63)) atomicAdd(Q.counter + 2, (unsigned)__builtin_popcountll(mr));
+            exact_assign_wslot(A, fr, mr, (uint32_t)q, 1u);
             asw_exact_push_wave(Q, fr, (uint32_t)(q + (xl - xr)), xl - xr, EXACT_SIDE_R, fr ? (uint32_t)(A.keyR[q] >> 32) : 0xffffffffu);
+        }
+    }
+}
+
+// 2b. the support weights of every flagged pixel towards its window, once: prox * exp(-dLab / gammaC) in the reference's expression
+// (_passive.cpp:47-50) -- the same instructions on the same operands as asw_exact_eval_kernel would execute per entry, so the same bits.
+// One wave per table slot.
+__global__ __launch_bounds__(256) void asw_exact_wtab_kernel(const AswExactArgs A)
+{
+#pragma clang fp contract(off)
+    __shared__ uint64_t s_exp[256];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) s_exp[k] = gm_exp_tab[k];
+    __syncthreads();
+    if (exact_overflowed(A)) return;
+    const unsigned n = min(A.q.counter[6], A.wcap);
+    const int lane = threadIdx.x & 63, W = A.W, H = A.H, win = A.win, p = A.pad, win2 = win * win;
+    for (unsigned slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += gridDim.x * 4) {
+        const uint32_t pw = A.wpix[slot], pix = pw & 0x7fffffffu;
+        const double *const lab = (pw >> 31) ? A.labR : A.labL;
+        const int yr = (int)(pix / (uint32_t)W), x = (int)(pix - (uint32_t)yr * (uint32_t)W), y = A.row0 + yr;
+        const double *const c = lab + 3 * ((size_t)y * W + x);
+        const double c0 = c[0], c1 = c[1], c2 = c[2];
+        double *const out = A.wtab + (size_t)slot * win2;
+        for (int t = lane; t < win2; t += 64) {
+            const int i = t / win, j = t - i * win, ii = y - p + i, cc = x - p + j;
+            double w = 0.0;
+            if ((unsigned)ii < (unsigned)H && (unsigned)cc < (unsigned)W) {
+                const double *const tp = lab + 3 * ((size_t)ii * W + cc);
+                const double a0 = tp[0] - c0, a1 = tp[1] - c1, a2 = tp[2] - c2;
+                w = A.prox[t] * glibc_exp_t(-exact_sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC, s_exp);
+            }
+            out[t] = w;
         }
     }
 }
@@ -353,6 +409,9 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
     double *const sw = s_w[wv], *const sc = s_c[wv];
     const unsigned n = min(A.q.counter[0], A.q.cap);
     const int W = A.W, H = A.H, win = A.win, p = A.pad;
+    // static stride over a grid of exactly the waves the chip holds at once (the launcher sizes it: five 4-wave groups per CU): a larger
+    // grid left its last round of waves to run after the others had finished (6 144 waves for 5 120 slots: ~1.7 x the ideal time).
+    // (Handing entries out through an atomic counter + readfirstlane hung the kernel on this compiler: not pursued.)
     for (unsigned e = blockIdx.x * EXACT_WAVES + wv; e < n; e += gridDim.x * EXACT_WAVES) {
         const u64 ent = A.q.entries[e];
         const uint32_t pix = (uint32_t)ent;
@@ -367,6 +426,11 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
         const int jlo = max(0, p - xr), jhi = min(win, W + p - x), ncol = jhi - jlo;
         const int ilo = max(0, p - y), ihi = min(win, H + p - y);
         const int ntap = (ihi - ilo) * ncol;
+        // weight tables (asw_exact_wtab_kernel): w1 of a flagged LEFT pixel, w2 of a flagged RIGHT pixel -- wave-uniform
+        const uint32_t s1 = A.wcap && A.q.flagL && A.q.flagL[pix] ? A.wslotL[pix] : 0xffffffffu;
+        const uint32_t s2 = A.wcap && A.q.flagR && A.q.flagR[pix - (uint32_t)d] ? A.wslotR[pix - (uint32_t)d] : 0xffffffffu;
+        const double *const t1 = s1 < A.wcap ? A.wtab + (size_t)s1 * win * win : nullptr;
+        const double *const t2 = s2 < A.wcap ? A.wtab + (size_t)s2 * win * win : nullptr;
         double acc = 0.0;                           // lane 0: cost, lane 1: tot
         // entries whose fp32 cost is 0 (EXACT_HINT_ZERO): if every in-image tap has TAD = 0 the reference's cost is exactly 0.0 --
         // `cost += w1*w2*0` for positive weights -- and nothing else has to be computed
@@ -385,12 +449,20 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void asw_exact_eval_kernel(const 
             for (int t = lane; t < nt; t += 64) {
                 const int q = (t0 + t) / ncol, i = ilo + q, j = jlo + (t0 + t - q * ncol);
                 const int ii = y - p + i, jj = xr - p + j, kk = x - p + j;
-                const double *const tl = A.labL + 3 * ((size_t)ii * W + kk), *const tr = A.labR + 3 * ((size_t)ii * W + jj);
                 const double pr = A.prox[i * win + j];
-                const double a0 = tl[0] - cl0, a1 = tl[1] - cl1, a2 = tl[2] - cl2;
-                const double b0 = tr[0] - cr0, b1 = tr[1] - cr1, b2 = tr[2] - cr2;
-                const double w1 = pr * glibc_exp_t(-exact_sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC, s_exp);
-                const double w2 = pr * glibc_exp_t(-exact_sqrt(b0 * b0 + b1 * b1 + b2 * b2) / A.gammaC, s_exp);
+                double w1, w2;
+                if (t1) w1 = t1[i * win + j];
+                else {
+                    const double *const tl = A.labL + 3 * ((size_t)ii * W + kk);
+                    const double a0 = tl[0] - cl0, a1 = tl[1] - cl1, a2 = tl[2] - cl2;
+                    w1 = pr * glibc_exp_t(-exact_sqrt(a0 * a0 + a1 * a1 + a2 * a2) / A.gammaC, s_exp);
+                }
+                if (t2) w2 = t2[i * win + j];
+                else {
+                    const double *const tr = A.labR + 3 * ((size_t)ii * W + jj);
+                    const double b0 = tr[0] - cr0, b1 = tr[1] - cr1, b2 = tr[2] - cr2;
+                    w2 = pr * glibc_exp_t(-exact_sqrt(b0 * b0 + b1 * b1 + b2 * b2) / A.gammaC, s_exp);
+                }
                 const int tad = min(40, (int)__builtin_amdgcn_sad_u8(A.recL[(size_t)ii * W + kk].bgrx, A.recR[(size_t)ii * W + jj].bgrx, 0u));
                 const double ww = w1 * w2;
                 sw[t] = ww;

@@ -251,7 +251,7 @@ struct Ctx {
     bool lut_ready = false;
     hipStream_t stream = nullptr;       // used by the host-buffer entry points
     DevBuf imgL, imgR, recL, recR, keyL, keyR, disp, costs, lab, altq, evol, altdisp;
-    DevBuf xlabL, xlabR, xflags, xqueue, xcost, xslots, xctr, xraw;      // fp64 tie-break pass (asw_exact_kernels.hip.h)
+    DevBuf xlabL, xlabR, xflags, xqueue, xcost, xslots, xctr, xraw, xwtab;      // fp64 tie-break pass (asw_exact_kernels.hip.h)
     unsigned int xcap = 0, xrawcap = 0; // queue capacities of the last exact call
     TableCache proxTabs{8}, gswTabs{4}, proxTabs64{8};
     std::map<const void *, int> max_dyn_lds;   // hipFuncAttributeMaxDynamicSharedMemorySize already granted per kernel
@@ -946,7 +946,7 @@ int asw_exact_prepare(Ctx &c, int W, int rows, int win, int nD, double gammaC, b
     int rc;
     // [64 B counters][flagL][flagR][zeroL][zeroR] (nout bytes each) [zrow rows]: one buffer, one memset
     if ((rc = c.xqueue.reserve(cap * 8)) || (rc = c.xcost.reserve(cap * 8)) || (rc = c.xflags.reserve(64 + 4 * nout + (size_t)rows)) ||
-        (rc = c.xslots.reserve(nout * 24)) || (rawcap && (rc = c.xraw.reserve(rawcap * 12))))
+        (rc = c.xslots.reserve(nout * 32)) || (rawcap && (rc = c.xraw.reserve(rawcap * 12))))
         return rc;
     c.xcap = (unsigned int)cap;
     c.xrawcap = (unsigned int)rawcap;
@@ -1009,6 +1009,17 @@ int asw_exact_pass(Ctx &c, const AswExactQueue &q, const AswExactQueue &raw, int
     x.ecost = (double *)c.xcost.ptr;
     x.costL = (u64 *)c.xslots.ptr; x.costR = x.costL + nout;
     x.idxL = (uint32_t *)(x.costR + nout); x.idxR = x.idxL + nout;
+    x.wslotL = x.idxR + nout; x.wslotR = x.wslotL + nout;
+    // weight tables of flagged pixels: up to 64 MB of them (6 800 pixels at a 35 x 35 window; the bench frame flags 133, the 4K frame 3 044)
+    {
+        const size_t per = (size_t)win * win * 8;
+        size_t wcap = std::min<size_t>(65536, ((size_t)64 << 20) / per);
+        if (nout >= ((size_t)1 << 31)) wcap = 0;
+        if (wcap && (rc = c.xwtab.reserve(wcap * 8 + wcap * per))) return rc;
+        x.wcap = (unsigned int)wcap;
+        x.wpix = (uint32_t *)c.xwtab.ptr;
+        x.wtab = (double *)((char *)c.xwtab.ptr + wcap * 8);
+    }
     x.H = H; x.W = W; x.win = win; x.pad = p; x.minD = minD; x.maxD = maxD; x.row0 = row0; x.rows = rows;
     x.gammaC = gammaC;
     Timed t(c, s, SSAMD_K_ASW_EXACT);
@@ -1032,7 +1043,8 @@ int asw_exact_pass(Ctx &c, const AswExactQueue &q, const AswExactQueue &raw, int
         hipLaunchKernelGGL(asw_exact_zero_kernel, dim3((unsigned)std::min<long long>(segs, 256 * 64)), dim3(256), zlds, s, x);
     }
     hipLaunchKernelGGL(asw_exact_winners_kernel, dim3(pb), dim3(256), 0, s, x);
-    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3(256 * 6), dim3(64 * EXACT_WAVES), 0, s, x);
+    if (x.wcap) hipLaunchKernelGGL(asw_exact_wtab_kernel, dim3(256 * 4), dim3(256), 0, s, x);
+    hipLaunchKernelGGL(asw_exact_eval_kernel, dim3((unsigned)(c.cus * 5)), dim3(64 * EXACT_WAVES), 0, s, x);      // five 4-wave groups per CU are resident (91 VGPRs)
     hipLaunchKernelGGL(asw_exact_resolve_kernel, dim3(256 * 4), dim3(256), 0, s, x);
     hipLaunchKernelGGL(asw_exact_patch_kernel, dim3(pb), dim3(256), 0, s, x);
     HIP_TRY(hipGetLastError());
@@ -2350,7 +2362,7 @@ int ssamd_debug_exact_costs(const uint8_t *img1, const uint8_t *img2, int height
         if (y < 0 || y >= height || x < 0 || x >= width || d < 0 || x - d < 0) return fail(SSAMD_EINVAL, "candidate %d outside the image", k);
         ent[k] = (u64)((uint32_t)y * (uint32_t)width + (uint32_t)x) | ((u64)(uint32_t)d << 32);       // sides = 0: cost only
     }
-    const unsigned int ctr[4] = {(unsigned int)n, 0, 0, 0};
+    const unsigned int ctr[16] = {(unsigned int)n};            // (counter[7] = the eval kernel's work counter)
     HIP_TRY(hipMemcpyAsync(c->xqueue.ptr, ent.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->xctr.ptr, ctr, sizeof(ctr), hipMemcpyHostToDevice, s));
     const double *d_prox = nullptr;
