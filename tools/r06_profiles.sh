@@ -8,12 +8,12 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/ben
 cp bench_details.json $O/bench_details.json
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline --no-others --no-e2e --no-bad1"
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o s -- $BENCH --steps 24 --warmup 2 > $O/stats.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_fp32 -o s -- $BENCH --fp32 --steps 24 --warmup 2 > $O/stats_fp32.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_cons -o s -- $BENCH --consistent --steps 12 --warmup 2 > $O/stats_cons.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_write.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d $O/pmc_valu -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_valu.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o s -- $BENCH --steps 24 --warmup 2 > $O/stats.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_fp32 -o s -- $BENCH --fp32 --steps 24 --warmup 2 > $O/stats_fp32.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_cons -o s -- $BENCH --consistent --steps 12 --warmup 2 > $O/stats_cons.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d $O/pmc_valu -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_valu.log 2>&1
 python - "$O" <<'PY'
 import csv, glob, json, os, sys, collections
 O = sys.argv[1]
