@@ -129,6 +129,9 @@ def test_bench_line_of_a_two_rank_run_explains_itself(tmp_path):
     compact, line = _read(r, env)
     assert compact["n_gpus"] == 2 and compact["rccl"]["world_size"] == 2 and len(compact["rccl"]["ranks"]) == 2
     assert compact["config"]["checksum_equals_single_gpu"] is True and compact["bad1_vs_cpu_ref"]["percent"] <= 0.5
+    # round 6: host time inside StripContext.step per rank (no synchronisation) and the exchange verdict travel in the compact line
+    assert 0 < compact["rccl"]["host_step_ms_max"] < 50 and all(r_["host_step_ms"] > 0 for r_ in compact["rccl"]["ranks"])
+    assert compact["bad1_vs_cpu_ref"]["differing_pixels"] == 0          # the default path through two strips: the reference's map
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     rc = line["rccl"]
     assert rc["world_size"] == 2 and len(rc["ranks"]) == 2 and "shared_gpu_test_mode" in rc
