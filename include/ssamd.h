@@ -136,7 +136,7 @@ int ssamd_gsw_device_rows2(const uint8_t *d_img1, const uint8_t *d_img2, int hei
  * wins, :90-93 / 243-246); both the left- and the right-referenced pass with `consistent`.  Scratch: O(H*W) (fp64 Lab images
  * 48 B / pixel, queue and slots 40 B / pixel; round 5 needed H*W*nD*4 bytes).  The weights are the reference's to the bit (glibc's
  * exp and powf restated for the device, csrc/glibc_math.hip.h; IEEE sqrt and division), so candidates one ulp apart resolve as in
- * the reference too: on the goldens, the whole bench frames and 38 642 random frames the map IS the reference's.  Among exactly
+ * the reference too: on the goldens, the whole bench frames and 77 000 random frames (rounds 5 and 6) the map IS the reference's.  Among exactly
  * equal fp64 costs the smallest index wins, as in ssamd_asw.  Candidates whose fp32 cost is exactly 0 are not queued: pixels with two
  * or more of them (the black margins of rectified frames) are settled by an integer test -- every in-image tap of the winner's window
  * has TAD = 0 => the reference's cost is exactly 0.0 and the winner is its first minimum -- and re-evaluated in full only where that
